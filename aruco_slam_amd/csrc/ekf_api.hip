@@ -1,0 +1,588 @@
+// C ABI of the EKF-SLAM HIP library (see include/ekf_slam_hip.h).
+// Host side only: argument checking, workspace carving, launch sequencing.
+#include "../../include/ekf_slam_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ekf_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess)                                                          \
+            return fail(EKF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+inline int64_t round_up(int64_t v, int64_t q) { return (v + q - 1) / q * q; }
+inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
+constexpr int kStageSlots = 64;   // pinned host ring for ekf_observe
+constexpr int kTimedKernels = 4;
+constexpr int kEventPool = 2048;  // frames of timing events kept before folding
+
+struct Layout {
+    int64_t cap;      // padded state dimension (multiple of 128)
+    int kmax;         // 3 * max_visible rounded up to 16
+    size_t elem;      // sizeof(cov element)
+    size_t off_jac, off_resid, off_y, off_lmcol, off_amat, off_lmat, off_dinv, off_wpanel, off_wdbg,
+        off_idx, off_z, off_status, off_diag, off_xyz, off_unc, total;
+};
+
+Layout make_layout(const ekf_config& c) {
+    Layout L{};
+    L.cap = round_up((int64_t)3 * c.max_landmarks + EKF_CAM, 128);
+    L.kmax = (int)round_up(3 * c.max_visible, EKF_RB);
+    L.elem = c.cov_dtype == EKF_COV_F32 ? 4 : 8;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o += align256(bytes); return at; };
+    L.off_jac = take((size_t)L.kmax * EKF_JLD * 8);
+    L.off_resid = take((size_t)L.kmax * 8);
+    L.off_y = take((size_t)L.kmax * 8);
+    L.off_lmcol = take((size_t)c.max_visible * 4);
+    L.off_amat = take((size_t)L.kmax * L.cap * 8);
+    L.off_lmat = take((size_t)L.kmax * L.kmax * 8);
+    L.off_dinv = take((size_t)L.kmax * EKF_RB * 8);
+    L.off_wpanel = take((size_t)L.kmax * L.cap * L.elem);
+    L.off_wdbg = take((size_t)L.kmax * L.cap * 8);
+    L.off_idx = take((size_t)c.max_visible * 4);
+    L.off_z = take((size_t)c.max_visible * 3 * 8);
+    L.off_status = take(256);
+    L.off_diag = take((size_t)L.cap * 8);
+    L.off_xyz = take((size_t)256 * 3 * 8);
+    L.off_unc = take((size_t)256 * 3 * 8);
+    L.total = o;
+    return L;
+}
+
+int check_config(const ekf_config* c) {
+    if (!c) return fail(EKF_ERR_INVALID, "config is NULL");
+    if (c->max_landmarks < 1) return fail(EKF_ERR_INVALID, "max_landmarks must be >= 1");
+    if (c->max_visible < 1 || c->max_visible > 64)
+        return fail(EKF_ERR_INVALID, "max_visible must be in 1..64");
+    if (c->cov_dtype != EKF_COV_F64 && c->cov_dtype != EKF_COV_F32)
+        return fail(EKF_ERR_INVALID, "cov_dtype must be EKF_COV_F64 or EKF_COV_F32");
+    if (c->quat_mode != EKF_QUAT_AS_WRITTEN && c->quat_mode != EKF_QUAT_SCALAR_FIRST)
+        return fail(EKF_ERR_INVALID, "unknown quat_mode");
+    if (c->cov_kernel < EKF_COVK_AUTO || c->cov_kernel > EKF_COVK_MFMA)
+        return fail(EKF_ERR_INVALID, "unknown cov_kernel");
+    if (!(c->r_uncertainty > 0.0)) return fail(EKF_ERR_INVALID, "r_uncertainty must be > 0");
+    return EKF_OK;
+}
+
+}  // namespace
+
+struct ekf_filter {
+    ekf_config cfg{};
+    Layout lay{};
+    hipStream_t stream = nullptr;
+    void* cov = nullptr;
+    int64_t ld = 0;
+    double* state = nullptr;
+    char* ws = nullptr;
+    bool bound = false, is_reset = false;
+    int n_lm = 0;
+    int last_m = 0;
+    bool debug_w = false;
+    // pinned staging ring for host-pointer observes
+    char* pinned = nullptr;
+    size_t slot_bytes = 0;
+    int slot = 0;
+    hipEvent_t slot_done[kStageSlots] = {};
+    // kernel timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev;   // (kTimedKernels + 1) per frame
+    int ev_frames = 0;
+    double t_sum_us[kTimedKernels] = {};
+    int64_t t_cnt[kTimedKernels] = {};
+
+    int dims() const { return 3 * n_lm + EKF_CAM; }
+    template <typename P> P* at(size_t off) const { return reinterpret_cast<P*>(ws + off); }
+};
+
+namespace {
+
+int fold_timing(ekf_filter* f) {
+    if (f->ev_frames == 0) return EKF_OK;
+    HIP_TRY(hipStreamSynchronize(f->stream));
+    for (int fr = 0; fr < f->ev_frames; ++fr) {
+        for (int kq = 0; kq < kTimedKernels; ++kq) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, f->ev[fr * (kTimedKernels + 1) + kq],
+                                        f->ev[fr * (kTimedKernels + 1) + kq + 1]));
+            f->t_sum_us[kq] += 1e3 * ms;
+            f->t_cnt[kq] += 1;
+        }
+    }
+    f->ev_frames = 0;
+    return EKF_OK;
+}
+
+EkfFrame make_frame(ekf_filter* f, const int32_t* idx_dev, const double* z_dev, int m,
+                    double* traj_row) {
+    EkfFrame fr{};
+    const Layout& L = f->lay;
+    fr.cov = f->cov;
+    fr.ld = f->ld;
+    fr.state = f->state;
+    fr.dims = f->dims();
+    fr.ncols = (int)round_up(fr.dims, 128);
+    fr.m = m;
+    fr.k = 3 * m;
+    fr.kpad = (int)round_up(fr.k, EKF_RB);
+    fr.idx = idx_dev;
+    fr.z = z_dev;
+    fr.jac = f->at<double>(L.off_jac);
+    fr.resid = f->at<double>(L.off_resid);
+    fr.lmcol = f->at<int32_t>(L.off_lmcol);
+    fr.amat = f->at<double>(L.off_amat);
+    fr.lda = L.cap;
+    fr.lmat = f->at<double>(L.off_lmat);
+    fr.ldl = L.kmax;
+    fr.dinv = f->at<double>(L.off_dinv);
+    fr.yvec = f->at<double>(L.off_y);
+    fr.wpanel = f->at<void>(L.off_wpanel);
+    fr.ldw = L.cap;
+    fr.wdbg = f->debug_w ? f->at<double>(L.off_wdbg) : nullptr;
+    fr.status = f->at<int32_t>(L.off_status);
+    fr.traj_row = traj_row;
+    fr.nz = EkfNoise{f->cfg.q_cam, f->cfg.q_err, f->cfg.q_lm, f->cfg.r_uncertainty};
+    fr.quat_mode = f->cfg.quat_mode;
+    return fr;
+}
+
+// predict + update for one frame: four dependent launches on the stream
+int enqueue_frame(ekf_filter* f, const int32_t* idx_dev, const double* z_dev, int m,
+                  double* traj_row) {
+    EkfFrame fr = make_frame(f, idx_dev, z_dev, m, traj_row);
+    const bool f32 = f->cfg.cov_dtype == EKF_COV_F32;
+    const int variant = f->cfg.cov_kernel == EKF_COVK_VALU ? 1 : 2;
+    hipEvent_t* ev = nullptr;
+    if (f->timing) {
+        if (f->ev_frames == kEventPool) {
+            int rc = fold_timing(f);
+            if (rc) return rc;
+        }
+        ev = &f->ev[f->ev_frames * (kTimedKernels + 1)];
+        f->ev_frames++;
+        HIP_TRY(hipEventRecord(ev[0], f->stream));
+    }
+    if (f32) ekf_launch_gather<float>(fr, f->stream); else ekf_launch_gather<double>(fr, f->stream);
+    if (ev) HIP_TRY(hipEventRecord(ev[1], f->stream));
+    ekf_launch_solve(fr, f->stream);
+    if (ev) HIP_TRY(hipEventRecord(ev[2], f->stream));
+    if (f32) ekf_launch_panel<float>(fr, f->stream); else ekf_launch_panel<double>(fr, f->stream);
+    if (ev) HIP_TRY(hipEventRecord(ev[3], f->stream));
+    if (f32) ekf_launch_cov_update<float>(fr, variant, f->stream);
+    else ekf_launch_cov_update<double>(fr, variant, f->stream);
+    if (ev) HIP_TRY(hipEventRecord(ev[4], f->stream));
+    HIP_TRY(hipGetLastError());
+    f->last_m = m;
+    return EKF_OK;
+}
+
+int check_ready(ekf_filter* f) {
+    if (!f) return fail(EKF_ERR_INVALID, "filter handle is NULL");
+    if (!f->bound) return fail(EKF_ERR_STATE, "ekf_bind_buffers has not been called");
+    if (!f->is_reset) return fail(EKF_ERR_STATE, "ekf_reset has not been called");
+    return EKF_OK;
+}
+
+int sync_and_check(ekf_filter* f) {
+    HIP_TRY(hipStreamSynchronize(f->stream));
+    int32_t st = 0;
+    HIP_TRY(hipMemcpy(&st, f->at<int32_t>(f->lay.off_status), sizeof(st), hipMemcpyDeviceToHost));
+    if (st != 0)
+        return fail(EKF_ERR_NUMERIC, "innovation covariance S was not positive definite");
+    return EKF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ekf_last_error_string(void) { return g_err.c_str(); }
+
+int ekf_default_config(ekf_config* cfg) {
+    if (!cfg) return fail(EKF_ERR_INVALID, "config is NULL");
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->max_landmarks = 50;   // DICT_5X5_50, base_filter.py:81-82
+    cfg->max_visible = 50;
+    cfg->cov_dtype = EKF_COV_F64;
+    cfg->quat_mode = EKF_QUAT_AS_WRITTEN;
+    cfg->cov_kernel = EKF_COVK_AUTO;
+    cfg->initial_camera_uncertainty = 0.1;
+    cfg->initial_landmark_uncertainty = 0.7;
+    cfg->r_uncertainty = 0.9;
+    cfg->q_cam = 0.3;
+    cfg->q_err = 0.5;
+    cfg->q_lm = 0.01;
+    cfg->stream = nullptr;
+    return EKF_OK;
+}
+
+int ekf_query_sizes(const ekf_config* cfg, int64_t* ld, size_t* cov_bytes, size_t* state_bytes,
+                    size_t* workspace_bytes) {
+    int rc = check_config(cfg);
+    if (rc) return rc;
+    Layout L = make_layout(*cfg);
+    if (ld) *ld = L.cap;
+    if (cov_bytes) *cov_bytes = (size_t)L.cap * L.cap * L.elem;
+    if (state_bytes) *state_bytes = (size_t)L.cap * 8;
+    if (workspace_bytes) *workspace_bytes = L.total;
+    return EKF_OK;
+}
+
+int ekf_create(const ekf_config* cfg, ekf_filter** out) {
+    int rc = check_config(cfg);
+    if (rc) return rc;
+    if (!out) return fail(EKF_ERR_INVALID, "out is NULL");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return fail(EKF_ERR_HIP, "no HIP device visible");
+    ekf_filter* f = new ekf_filter();
+    f->cfg = *cfg;
+    f->lay = make_layout(*cfg);
+    f->stream = static_cast<hipStream_t>(cfg->stream);
+    f->slot_bytes = align256((size_t)cfg->max_visible * 4) + align256((size_t)cfg->max_visible * 24);
+    if (f->slot_bytes < align256(256 * 24) * 2) f->slot_bytes = align256(256 * 24) * 2;
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&f->pinned), f->slot_bytes * kStageSlots,
+                                 hipHostMallocDefault);
+    if (e != hipSuccess) {
+        delete f;
+        return fail(EKF_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    }
+    for (int i = 0; i < kStageSlots; ++i) {
+        e = hipEventCreateWithFlags(&f->slot_done[i], hipEventDisableTiming);
+        if (e != hipSuccess) {
+            ekf_destroy(f);
+            return fail(EKF_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e));
+        }
+    }
+    *out = f;
+    return EKF_OK;
+}
+
+int ekf_destroy(ekf_filter* f) {
+    if (!f) return EKF_OK;
+    (void)hipStreamSynchronize(f->stream);
+    for (auto& e : f->ev) (void)hipEventDestroy(e);
+    for (int i = 0; i < kStageSlots; ++i)
+        if (f->slot_done[i]) (void)hipEventDestroy(f->slot_done[i]);
+    if (f->pinned) (void)hipHostFree(f->pinned);
+    delete f;
+    return EKF_OK;
+}
+
+int ekf_bind_buffers(ekf_filter* f, void* cov_dev, int64_t ld, double* state_dev, void* workspace_dev,
+                     size_t workspace_bytes) {
+    if (!f) return fail(EKF_ERR_INVALID, "filter handle is NULL");
+    if (!cov_dev || !state_dev || !workspace_dev) return fail(EKF_ERR_INVALID, "NULL device buffer");
+    if (ld != f->lay.cap) return fail(EKF_ERR_INVALID, "ld must equal the value from ekf_query_sizes");
+    if (workspace_bytes < f->lay.total) return fail(EKF_ERR_INVALID, "workspace too small");
+    if ((reinterpret_cast<uintptr_t>(cov_dev) | reinterpret_cast<uintptr_t>(workspace_dev) |
+         reinterpret_cast<uintptr_t>(state_dev)) & 0xFF)
+        return fail(EKF_ERR_INVALID, "device buffers must be 256-byte aligned");
+    f->cov = cov_dev;
+    f->ld = ld;
+    f->state = state_dev;
+    f->ws = static_cast<char*>(workspace_dev);
+    f->bound = true;
+    f->is_reset = false;
+    return EKF_OK;
+}
+
+int ekf_reset(ekf_filter* f, const double initial_camera_pose[10]) {
+    if (!f) return fail(EKF_ERR_INVALID, "filter handle is NULL");
+    if (!f->bound) return fail(EKF_ERR_STATE, "ekf_bind_buffers has not been called");
+    if (!initial_camera_pose) return fail(EKF_ERR_INVALID, "initial pose is NULL");
+    const Layout& L = f->lay;
+    HIP_TRY(hipStreamSynchronize(f->stream));
+    HIP_TRY(hipMemsetAsync(f->cov, 0, (size_t)L.cap * L.cap * L.elem, f->stream));
+    HIP_TRY(hipMemsetAsync(f->state, 0, (size_t)L.cap * 8, f->stream));
+    HIP_TRY(hipMemsetAsync(f->ws, 0, L.total, f->stream));
+    HIP_TRY(hipMemcpyAsync(f->state, initial_camera_pose, 10 * sizeof(double), hipMemcpyHostToDevice,
+                           f->stream));
+    // P = 0.1 I_10  (extended_kalman_filter.py:48)
+    char diag[8 * EKF_CAM];
+    for (int i = 0; i < EKF_CAM; ++i) {
+        if (L.elem == 4) reinterpret_cast<float*>(diag)[i] = (float)f->cfg.initial_camera_uncertainty;
+        else reinterpret_cast<double*>(diag)[i] = f->cfg.initial_camera_uncertainty;
+    }
+    HIP_TRY(hipMemcpy2DAsync(f->cov, (size_t)(L.cap + 1) * L.elem, diag, L.elem, L.elem, EKF_CAM,
+                             hipMemcpyHostToDevice, f->stream));
+    HIP_TRY(hipStreamSynchronize(f->stream));
+    f->n_lm = 0;
+    f->last_m = 0;
+    f->is_reset = true;
+    return EKF_OK;
+}
+
+int ekf_add_markers(ekf_filter* f, const double* cam_frame_xyz, const double* diag_uncertainty,
+                    int32_t count) {
+    int rc = check_ready(f);
+    if (rc) return rc;
+    if (count < 0 || (count > 0 && !cam_frame_xyz)) return fail(EKF_ERR_INVALID, "bad marker list");
+    if (f->n_lm + count > f->cfg.max_landmarks)
+        return fail(EKF_ERR_CAPACITY, "more landmarks than max_landmarks");
+    const Layout& L = f->lay;
+    int done = 0;
+    while (done < count) {
+        const int chunk = std::min(256, count - done);
+        char* slot = f->pinned + (size_t)f->slot * f->slot_bytes;
+        HIP_TRY(hipEventSynchronize(f->slot_done[f->slot]));
+        double* hx = reinterpret_cast<double*>(slot);
+        double* hu = reinterpret_cast<double*>(slot + align256(256 * 24));
+        std::memcpy(hx, cam_frame_xyz + 3 * done, (size_t)chunk * 24);
+        if (diag_uncertainty) std::memcpy(hu, diag_uncertainty + 3 * done, (size_t)chunk * 24);
+        HIP_TRY(hipMemcpyAsync(f->at<double>(L.off_xyz), hx, (size_t)chunk * 24, hipMemcpyHostToDevice,
+                               f->stream));
+        if (diag_uncertainty)
+            HIP_TRY(hipMemcpyAsync(f->at<double>(L.off_unc), hu, (size_t)chunk * 24,
+                                   hipMemcpyHostToDevice, f->stream));
+        const double* unc_dev = diag_uncertainty ? f->at<double>(L.off_unc) : nullptr;
+        if (L.elem == 4)
+            ekf_launch_add_markers<float>(f->cov, f->ld, f->state, f->dims(), f->at<double>(L.off_xyz),
+                                          unc_dev, f->cfg.initial_landmark_uncertainty, chunk, f->stream);
+        else
+            ekf_launch_add_markers<double>(f->cov, f->ld, f->state, f->dims(), f->at<double>(L.off_xyz),
+                                           unc_dev, f->cfg.initial_landmark_uncertainty, chunk,
+                                           f->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(f->slot_done[f->slot], f->stream));
+        f->slot = (f->slot + 1) % kStageSlots;
+        f->n_lm += chunk;
+        done += chunk;
+    }
+    return EKF_OK;
+}
+
+int ekf_observe(ekf_filter* f, const int32_t* lm_index, const double* z, int32_t m) {
+    int rc = check_ready(f);
+    if (rc) return rc;
+    if (m < 1) return fail(EKF_ERR_INVALID, "observe needs at least one detection");
+    if (m > f->cfg.max_visible) return fail(EKF_ERR_CAPACITY, "more detections than max_visible");
+    if (!lm_index || !z) return fail(EKF_ERR_INVALID, "NULL detections");
+    for (int i = 0; i < m; ++i)
+        if (lm_index[i] < 0 || lm_index[i] >= f->n_lm)
+            return fail(EKF_ERR_INVALID, "landmark index out of range");
+    const Layout& L = f->lay;
+    char* slot = f->pinned + (size_t)f->slot * f->slot_bytes;
+    HIP_TRY(hipEventSynchronize(f->slot_done[f->slot]));
+    int32_t* hidx = reinterpret_cast<int32_t*>(slot);
+    double* hz = reinterpret_cast<double*>(slot + align256((size_t)f->cfg.max_visible * 4));
+    std::memcpy(hidx, lm_index, (size_t)m * 4);
+    std::memcpy(hz, z, (size_t)m * 24);
+    HIP_TRY(hipMemcpyAsync(f->at<int32_t>(L.off_idx), hidx, (size_t)m * 4, hipMemcpyHostToDevice,
+                           f->stream));
+    HIP_TRY(hipMemcpyAsync(f->at<double>(L.off_z), hz, (size_t)m * 24, hipMemcpyHostToDevice,
+                           f->stream));
+    rc = enqueue_frame(f, f->at<int32_t>(L.off_idx), f->at<double>(L.off_z), m, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(f->slot_done[f->slot], f->stream));
+    f->slot = (f->slot + 1) % kStageSlots;
+    return EKF_OK;
+}
+
+int ekf_observe_device(ekf_filter* f, const int32_t* lm_index_dev, const double* z_dev, int32_t m) {
+    int rc = check_ready(f);
+    if (rc) return rc;
+    if (m < 1) return fail(EKF_ERR_INVALID, "observe needs at least one detection");
+    if (m > f->cfg.max_visible) return fail(EKF_ERR_CAPACITY, "more detections than max_visible");
+    if (!lm_index_dev || !z_dev) return fail(EKF_ERR_INVALID, "NULL detections");
+    return enqueue_frame(f, lm_index_dev, z_dev, m, nullptr);
+}
+
+int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, const double* z_dev,
+                                int32_t m, int32_t frames, double* trajectory_dev) {
+    int rc = check_ready(f);
+    if (rc) return rc;
+    if (m < 1 || frames < 0) return fail(EKF_ERR_INVALID, "bad sequence shape");
+    if (m > f->cfg.max_visible) return fail(EKF_ERR_CAPACITY, "more detections than max_visible");
+    if (!lm_index_dev || !z_dev) return fail(EKF_ERR_INVALID, "NULL detections");
+    for (int t = 0; t < frames; ++t) {
+        rc = enqueue_frame(f, lm_index_dev + (size_t)t * m, z_dev + (size_t)t * m * 3, m,
+                           trajectory_dev ? trajectory_dev + (size_t)t * 7 : nullptr);
+        if (rc) return rc;
+    }
+    return EKF_OK;
+}
+
+int ekf_sync(ekf_filter* f) {
+    int rc = check_ready(f);
+    if (rc) return rc;
+    return sync_and_check(f);
+}
+
+int ekf_num_landmarks(const ekf_filter* f) { return f ? f->n_lm : EKF_ERR_INVALID; }
+
+int ekf_get_state(ekf_filter* f, double* out, int32_t count) {
+    int rc = check_ready(f);
+    if (rc) return rc;
+    if (!out || count < 0 || count > f->dims()) return fail(EKF_ERR_INVALID, "bad state request");
+    rc = sync_and_check(f);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out, f->state, (size_t)count * 8, hipMemcpyDeviceToHost));
+    return EKF_OK;
+}
+
+int ekf_get_camera(ekf_filter* f, double out[10]) { return ekf_get_state(f, out, EKF_CAM); }
+
+int ekf_get_cov_diag(ekf_filter* f, double* out, int32_t count) {
+    int rc = check_ready(f);
+    if (rc) return rc;
+    if (!out || count < 0 || count > f->dims()) return fail(EKF_ERR_INVALID, "bad diag request");
+    double* scratch = f->at<double>(f->lay.off_diag);
+    if (f->lay.elem == 4) ekf_launch_cov_diag<float>(f->cov, f->ld, scratch, count, f->stream);
+    else ekf_launch_cov_diag<double>(f->cov, f->ld, scratch, count, f->stream);
+    HIP_TRY(hipGetLastError());
+    rc = sync_and_check(f);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out, scratch, (size_t)count * 8, hipMemcpyDeviceToHost));
+    return EKF_OK;
+}
+
+int ekf_get_cov(ekf_filter* f, double* out, int32_t dims) {
+    int rc = check_ready(f);
+    if (rc) return rc;
+    if (!out || dims != f->dims()) return fail(EKF_ERR_INVALID, "dims must equal 3*num_landmarks+10");
+    rc = sync_and_check(f);
+    if (rc) return rc;
+    const size_t el = f->lay.elem;
+    if (el == 8) {
+        HIP_TRY(hipMemcpy2D(out, (size_t)dims * 8, f->cov, (size_t)f->ld * 8, (size_t)dims * 8, dims,
+                            hipMemcpyDeviceToHost));
+    } else {
+        std::vector<float> tmp((size_t)dims * dims);
+        HIP_TRY(hipMemcpy2D(tmp.data(), (size_t)dims * 4, f->cov, (size_t)f->ld * 4, (size_t)dims * 4,
+                            dims, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < tmp.size(); ++i) out[i] = (double)tmp[i];
+    }
+    return EKF_OK;
+}
+
+int ekf_set_state(ekf_filter* f, const double* state, int32_t num_landmarks) {
+    int rc = check_ready(f);
+    if (rc) return rc;
+    if (!state || num_landmarks < 0) return fail(EKF_ERR_INVALID, "bad state");
+    if (num_landmarks > f->cfg.max_landmarks)
+        return fail(EKF_ERR_CAPACITY, "more landmarks than max_landmarks");
+    HIP_TRY(hipStreamSynchronize(f->stream));
+    HIP_TRY(hipMemset(f->state, 0, (size_t)f->lay.cap * 8));
+    HIP_TRY(hipMemcpy(f->state, state, (size_t)(3 * num_landmarks + EKF_CAM) * 8,
+                      hipMemcpyHostToDevice));
+    f->n_lm = num_landmarks;
+    return EKF_OK;
+}
+
+int ekf_set_cov(ekf_filter* f, const double* cov, int32_t dims) {
+    int rc = check_ready(f);
+    if (rc) return rc;
+    if (!cov || dims != f->dims())
+        return fail(EKF_ERR_INVALID, "dims must equal 3*num_landmarks+10 (call ekf_set_state first)");
+    const Layout& L = f->lay;
+    HIP_TRY(hipStreamSynchronize(f->stream));
+    HIP_TRY(hipMemset(f->cov, 0, (size_t)L.cap * L.cap * L.elem));
+    // symmetrise on upload: the kernels keep P bitwise symmetric from then on
+    if (L.elem == 8) {
+        std::vector<double> tmp((size_t)dims * dims);
+        for (int i = 0; i < dims; ++i)
+            for (int j = 0; j < dims; ++j)
+                tmp[(size_t)i * dims + j] = 0.5 * (cov[(size_t)i * dims + j] + cov[(size_t)j * dims + i]);
+        HIP_TRY(hipMemcpy2D(f->cov, (size_t)f->ld * 8, tmp.data(), (size_t)dims * 8, (size_t)dims * 8,
+                            dims, hipMemcpyHostToDevice));
+    } else {
+        std::vector<float> tmp((size_t)dims * dims);
+        for (int i = 0; i < dims; ++i)
+            for (int j = 0; j < dims; ++j)
+                tmp[(size_t)i * dims + j] =
+                    (float)(0.5 * (cov[(size_t)i * dims + j] + cov[(size_t)j * dims + i]));
+        HIP_TRY(hipMemcpy2D(f->cov, (size_t)f->ld * 4, tmp.data(), (size_t)dims * 4, (size_t)dims * 4,
+                            dims, hipMemcpyHostToDevice));
+    }
+    return EKF_OK;
+}
+
+int ekf_set_kernel_timing(ekf_filter* f, int32_t enable) {
+    if (!f) return fail(EKF_ERR_INVALID, "filter handle is NULL");
+    HIP_TRY(hipStreamSynchronize(f->stream));
+    if (enable && f->ev.empty()) {
+        f->ev.resize((size_t)kEventPool * (kTimedKernels + 1));
+        for (auto& e : f->ev) HIP_TRY(hipEventCreate(&e));
+    }
+    f->timing = enable != 0;
+    f->ev_frames = 0;
+    for (int i = 0; i < kTimedKernels; ++i) {
+        f->t_sum_us[i] = 0.0;
+        f->t_cnt[i] = 0;
+    }
+    return EKF_OK;
+}
+
+int ekf_get_kernel_timing(ekf_filter* f, int32_t which, double* mean_us, int64_t* launches) {
+    if (!f) return fail(EKF_ERR_INVALID, "filter handle is NULL");
+    if (which < 0 || which >= kTimedKernels) return fail(EKF_ERR_INVALID, "which must be 0..3");
+    int rc = fold_timing(f);
+    if (rc) return rc;
+    if (mean_us) *mean_us = f->t_cnt[which] ? f->t_sum_us[which] / (double)f->t_cnt[which] : 0.0;
+    if (launches) *launches = f->t_cnt[which];
+    return EKF_OK;
+}
+
+int ekf_debug_fetch(ekf_filter* f, int32_t what, double* out, size_t count) {
+    int rc = check_ready(f);
+    if (rc) return rc;
+    if (!out) return fail(EKF_ERR_INVALID, "out is NULL");
+    if (what == -1) {           // enable the f64 copy of W in subsequent frames
+        f->debug_w = true;
+        return EKF_OK;
+    }
+    const Layout& L = f->lay;
+    const int k = 3 * f->last_m, kp = (int)round_up(k, EKF_RB), dims = f->dims();
+    HIP_TRY(hipStreamSynchronize(f->stream));
+    switch (what) {
+        case 0:
+            if (count < (size_t)k * EKF_JCOLS) return fail(EKF_ERR_INVALID, "out too small");
+            HIP_TRY(hipMemcpy2D(out, EKF_JCOLS * 8, f->at<double>(L.off_jac), EKF_JLD * 8, EKF_JCOLS * 8,
+                                k, hipMemcpyDeviceToHost));
+            return EKF_OK;
+        case 1:
+            if (count < (size_t)k) return fail(EKF_ERR_INVALID, "out too small");
+            HIP_TRY(hipMemcpy(out, f->at<double>(L.off_resid), (size_t)k * 8, hipMemcpyDeviceToHost));
+            return EKF_OK;
+        case 2:
+            if (count < (size_t)kp * kp) return fail(EKF_ERR_INVALID, "out too small");
+            HIP_TRY(hipMemcpy2D(out, (size_t)kp * 8, f->at<double>(L.off_lmat), (size_t)L.kmax * 8,
+                                (size_t)kp * 8, kp, hipMemcpyDeviceToHost));
+            return EKF_OK;
+        case 3:
+            if (!f->debug_w) return fail(EKF_ERR_STATE, "call ekf_debug_fetch(f,-1,..) first");
+            if (count < (size_t)kp * dims) return fail(EKF_ERR_INVALID, "out too small");
+            HIP_TRY(hipMemcpy2D(out, (size_t)dims * 8, f->at<double>(L.off_wdbg), (size_t)L.cap * 8,
+                                (size_t)dims * 8, kp, hipMemcpyDeviceToHost));
+            return EKF_OK;
+        case 4:
+            if (count < (size_t)k * dims) return fail(EKF_ERR_INVALID, "out too small");
+            HIP_TRY(hipMemcpy2D(out, (size_t)dims * 8, f->at<double>(L.off_amat), (size_t)L.cap * 8,
+                                (size_t)dims * 8, k, hipMemcpyDeviceToHost));
+            return EKF_OK;
+        default:
+            return fail(EKF_ERR_INVALID, "unknown debug item");
+    }
+}
+
+}  // extern "C"

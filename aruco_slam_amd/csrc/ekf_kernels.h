@@ -1,0 +1,50 @@
+// Host-visible launch interface of the EKF kernels (internal to the library).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ekf_device.h"
+
+// Everything one frame's kernels need; passed by value.
+struct EkfFrame {
+    void* cov;             // P, f32 or f64, row-major, leading dim ld
+    int64_t ld;
+    double* state;         // [cap]
+    int32_t dims;          // N = 3 n + 10
+    int32_t ncols;         // N rounded up to 128 (<= ld): columns the panel covers
+    int32_t m;             // detections this frame
+    int32_t k;             // 3 m
+    int32_t kpad;          // k rounded up to EKF_RB
+    const int32_t* idx;    // [m] landmark indices (device)
+    const double* z;       // [m,3] measured positions, camera frame (device)
+    double* jac;           // [kmax, EKF_JLD] Jacobian rows (13 used)
+    double* resid;         // [kmax] z - h
+    int32_t* lmcol;        // [mmax] first state column of each detection
+    double* amat;          // A = H (P+Q), [kmax, lda] f64
+    int64_t lda;
+    double* lmat;          // Cholesky factor L of S, [kmax, ldl] f64 (lower)
+    int32_t ldl;
+    double* dinv;          // inverse of the 16x16 diagonal blocks of L, [kmax/16,16,16]
+    double* yvec;          // L^-1 (z - h), [kmax]
+    void* wpanel;          // W = L^-1 A, [kmax, ldw], cov dtype, k-major
+    int64_t ldw;
+    double* wdbg;          // optional f64 copy of W for tests (may be null)
+    int32_t* status;       // [0] != 0 -> non-SPD innovation covariance seen
+    double* traj_row;      // optional: state[0:7] after the update
+    EkfNoise nz;
+    int32_t quat_mode;
+};
+
+template <typename T> void ekf_launch_gather(const EkfFrame& fr, hipStream_t s);
+void ekf_launch_solve(const EkfFrame& fr, hipStream_t s);
+template <typename T> void ekf_launch_panel(const EkfFrame& fr, hipStream_t s);
+// P <- P + Q - W^T W.  variant: 1 = VALU reference kernel, 2 = MFMA kernel.
+template <typename T> void ekf_launch_cov_update(const EkfFrame& fr, int variant, hipStream_t s);
+
+template <typename T>
+void ekf_launch_add_markers(void* cov, int64_t ld, double* state, int32_t dims,
+                            const double* xyz_dev, const double* unc_dev, double default_unc,
+                            int32_t count, hipStream_t s);
+template <typename T>
+void ekf_launch_cov_diag(const void* cov, int64_t ld, double* out_dev, int32_t count, hipStream_t s);
+int ekf_solve_lds_bytes(int kpad);
+int ekf_panel_lds_bytes(int kpad);

@@ -1,0 +1,173 @@
+"""Filter boundary: host-side mirror of reference ``BaseFilter``
+(/root/reference/filters/base_filter.py:35-381).
+
+Only the boundary is in scope: the abstract filter API,
+the ``process_frame`` driver contract (observe only when something was
+detected, ``get_poses`` every frame -- base_filter.py:194-212) and the map file
+format (``save_map`` :214-247).  The ArUco detector / solvePnP front-end is
+OpenCV work and is not re-implemented; when ``cv2`` is importable it is used
+exactly as the reference does, otherwise frames of pre-computed detections
+are fed through ``process_detections``.
+"""
+from __future__ import annotations
+
+from pathlib import Path
+
+import numpy as np
+
+try:  # the image has no OpenCV; the boundary does not need it
+    import cv2  # type: ignore
+except ImportError:  # pragma: no cover
+    cv2 = None
+
+CALIB_MTX_FILE = "./calibration/camera_matrix.npy"      # base_filter.py:12
+DIST_COEFFS_FILE = "./calibration/dist_coeffs.npy"      # base_filter.py:13
+
+KALMAN_FILTER = "ekf"
+FACTOR_GRAPH = "factorgraph"
+
+NOT_IMPLEMENTED_ERROR = """
+                        This method is not implemented in the base class and
+                        should be implemented in a subclass.
+                        """
+
+CAM_DIMS = 10
+XYZ_DIMS = slice(0, 3)
+QUAT_DIMS = slice(3, 7)
+ERROR_DIMS = slice(7, 10)
+
+
+class BaseFilter:
+    """Front-end + abstract back-end API (names and semantics of the reference)."""
+
+    def __init__(self, initial_pose, map_file=None, aruco_dict=None) -> None:
+        self.calib_matrix = None
+        self.dist_coeffs = None
+        self.detector = None
+        if cv2 is not None:
+            # same contract as base_filter.py:55-67
+            if not Path(CALIB_MTX_FILE).exists():
+                raise FileNotFoundError("Camera matrix not found. Run calibration.py first.")
+            if not Path(DIST_COEFFS_FILE).exists():
+                raise FileNotFoundError(
+                    "Distortion coefficients not found. Run calibration.py first.")
+            self.calib_matrix = np.load(CALIB_MTX_FILE)
+            self.dist_coeffs = np.load(DIST_COEFFS_FILE)
+            self.detector = self.init_aruco_detector(aruco_dict)
+        self.camera_pose = initial_pose
+        self._map_file = map_file
+
+    def _load_initial_map(self):
+        """Subclasses call this once their back-end exists (the reference calls
+        load_map from the base ctor, base_filter.py:71-72, before the subclass
+        state exists -- one reason its load_map never worked)."""
+        if self._map_file is not None:
+            self.load_map(self._map_file)
+
+    def init_aruco_detector(self, aruco_dict):
+        """base_filter.py:74-90 (needs OpenCV)."""
+        if cv2 is None:
+            raise RuntimeError("OpenCV (cv2) is not available: feed detections via "
+                               "process_detections()")
+        if aruco_dict is None:
+            aruco_dict = cv2.aruco.DICT_5X5_50
+        aruco_dict = cv2.aruco.getPredefinedDictionary(aruco_dict)
+        params = cv2.aruco.DetectorParameters()
+        params.cornerRefinementMethod = cv2.aruco.CORNER_REFINE_SUBPIX
+        params.cornerRefinementWinSize = 3
+        params.cornerRefinementMaxIterations = 3
+        params.adaptiveThreshWinSizeMin = 3
+        params.adaptiveThreshWinSizeMax = 30
+        return cv2.aruco.ArucoDetector(aruco_dict, params)
+
+    def estimate_pose_of_markers(self, corners, ids, marker_size):
+        """base_filter.py:92-171: IPPE-square PnP per marker -> (m,6) [tvec|rvec]."""
+        if cv2 is None:
+            raise RuntimeError("OpenCV (cv2) is not available")
+        half = marker_size / 2
+        marker_points = np.array([[-half, half, 0], [half, half, 0], [half, -half, 0],
+                                  [-half, -half, 0]], dtype=np.float32)
+        out = np.zeros((len(ids), 6))
+        for j, c in enumerate(corners):
+            _, rot, t = cv2.solvePnP(marker_points, c, self.calib_matrix, self.dist_coeffs,
+                                     rvec=None, useExtrinsicGuess=False,
+                                     flags=cv2.SOLVEPNP_IPPE_SQUARE)
+            out[j, 0:3] = t.flatten()
+            out[j, 3:6] = rot.flatten()
+        return out
+
+    def process_frame(self, frame, should_filter=True, iteration=0, marker_size=0.16):
+        """base_filter.py:173-212."""
+        if self.detector is None:
+            raise RuntimeError("no ArUco detector (cv2 missing): use process_detections()")
+        corners, ids, _ = tuple(self.detector.detectMarkers(frame))
+        detected_poses = np.array([])
+        if ids is not None:
+            frame = cv2.aruco.drawDetectedMarkers(frame, corners, ids)
+            ids = ids.flatten()
+            detected_poses = self.estimate_pose_of_markers(corners, ids, marker_size)
+        _, camera_pose, marker_poses, detected_poses = self.process_detections(
+            ids, detected_poses, should_filter, iteration)
+        return frame, camera_pose, marker_poses, detected_poses
+
+    def process_detections(self, ids, detected_poses, should_filter=True, iteration=0):
+        """The part of ``process_frame`` behind the detector
+        (base_filter.py:196-212): ``ids`` is None for a frame without
+        detections, in which case the filter is NOT stepped (no predict)."""
+        if ids is None:
+            detected_poses = np.array([])
+        elif should_filter:
+            self.observe(ids, detected_poses)
+        if should_filter:
+            camera_pose, marker_poses = self.get_poses()
+        else:
+            _, marker_poses = self.get_poses()
+            camera_pose = self.get_cam_estimate(iteration)
+        return None, camera_pose, marker_poses, detected_poses
+
+    def save_map(self, filename: str) -> None:
+        """Map text format of base_filter.py:214-247: three comment lines and a
+        blank, then per landmark (index order) ``id``, ``x, y, z``,
+        ``ux, uy, uz`` and a blank line; numbers via ``str()``."""
+        _, marker_poses = self.get_poses()
+        index_to_id = {v: k for k, v in self.get_lm_estimates()}
+        uncertainties = self.get_lm_uncertainties()
+        with Path(filename).open("w", encoding="utf-8") as file:
+            file.write("# landmark_id\n")
+            file.write("# x y z\n")
+            file.write("# uncertainty\n")
+            file.write("\n")
+            for i, pose in enumerate(marker_poses):
+                file.write(f"{index_to_id[i]}\n")
+                file.write(f"{', '.join(map(str, pose))}\n")
+                file.write(f"{', '.join(map(str, uncertainties[i, :len(pose)]))}\n")
+                file.write("\n")
+
+    def load_map(self, filename: str) -> None:
+        """Reader for the ``save_map`` format (base_filter.py:249-272: skip 4
+        header lines, stride 4).  The reference's version ends in
+        ``self.filter.add_marker`` (an AttributeError, :272); this one calls the
+        intended restore hook ``self.add_marker(id, pose, uncertainty)``."""
+        with Path(filename).open("r", encoding="utf-8") as file:
+            lines = file.readlines()[4:]
+        for i in range(0, len(lines) - 2, 4):
+            id_ = int(lines[i].strip())
+            pose = np.array(lines[i + 1].strip().split(", "), np.float64)
+            uncertainty = np.array(lines[i + 2].strip().split(", "), np.float64)
+            self.add_marker(id_, pose, uncertainty)
+
+    # -- abstract back-end API, base_filter.py:327-381 ------------------------
+    def observe(self, ids, poses) -> None:
+        raise NotImplementedError(NOT_IMPLEMENTED_ERROR)
+
+    def get_poses(self):
+        raise NotImplementedError(NOT_IMPLEMENTED_ERROR)
+
+    def get_lm_uncertainties(self):
+        raise NotImplementedError(NOT_IMPLEMENTED_ERROR)
+
+    def get_lm_estimates(self):
+        raise NotImplementedError(NOT_IMPLEMENTED_ERROR)
+
+    def get_cam_estimate(self, iteration: int):
+        raise NotImplementedError(NOT_IMPLEMENTED_ERROR)

@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Benchmark of the EKF-SLAM update path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one ``observe()`` (predict + update) of the headline workload
+(BASELINE.json configs[2]): n=1024 landmarks, m=32 detections per frame,
+fp32 covariance / fp64 state, synthetic detections already resident in HBM.
+With N > 1 (launched by torch.distributed.run) every rank runs its own
+independent sequence (seed = rank) on its own GPU -- the path shards by
+sequence, there is no collective in the frame loop -- and the trajectory and
+map are gathered once at the end over RCCL ("scaling": "weak").
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     : covariance-update kernel (P <- P + Q - W^T W), algorithmic
+                 bytes 2 N^2 sizeof(T) per launch / mean launch duration measured
+                 with HIP events on the filter's stream in an instrumented
+                 repeat of the timed steps
+  cpu_baseline : the CPU oracle in the reference's own operation sequence
+                 (oracle/ekf_numpy.py, mode="reference_ops") timed on this
+                 host on a bounded sample of the same workload (N=1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+INIT_POSE = np.array([0, 0, 0, 1, 0, 0, 0, 0, 0, 0])
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--landmarks", type=int, default=1024)
+    ap.add_argument("--visible", type=int, default=32)
+    ap.add_argument("--cov-dtype", default="float32", choices=["float32", "float64"])
+    ap.add_argument("--cov-kernel", default="auto", choices=["auto", "valu", "mfma"])
+    ap.add_argument("--cpu-frames", type=int, default=12,
+                    help="steady-state frames of the CPU baseline sample (0 = skip)")
+    return ap.parse_args()
+
+
+def cpu_baseline(n, m, frames):
+    """Reference-ops oracle on the same stream (seed 0): bootstrap untimed
+    (fast mode, same results), then `frames` timed steady-state updates."""
+    from aruco_slam_amd.synthetic import SyntheticStream
+    from oracle.ekf_numpy import OracleEKF
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    stream = SyntheticStream(n, m, seed=0)
+    orc = OracleEKF(INIT_POSE, mode="fast")
+    for ids, poses in stream.bootstrap():
+        orc.observe(list(ids), poses)
+    orc.mode = "reference_ops"
+    cams, per = [], []
+    for ids, poses in stream.steady(frames):
+        t0 = time.perf_counter()
+        orc.observe(list(ids), poses)
+        per.append(time.perf_counter() - t0)
+        cams.append(np.asarray(orc.state[:7], dtype=np.float64).copy())
+    per = np.asarray(per)
+    steady = per[1:] if len(per) > 2 else per          # first frame pays allocator warm-up
+    return {
+        "value": float(1.0 / steady.mean()), "unit": "updates/s", "cores": int(threads),
+        "kind": "port",
+        "sample": (f"{frames} steady-state frames (first discarded) of the same n={n}, m={m} "
+                   f"stream, NumPy/SciPy restatement in the reference's op sequence "
+                   f"(dense Q, CSR of P, spsolve, dense (I-KH)P), host cpu_count={os.cpu_count()}"),
+        "ms_per_update": float(1e3 * steady.mean()),
+    }, np.stack(cams)
+
+
+def main():
+    args = parse_args()
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N "
+                             "bench.py --gpus N ...")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the EKF path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    from aruco_slam_amd.filters.extended_kalman_filter import EKF
+    from aruco_slam_amd.synthetic import SyntheticStream
+
+    n, m, k_steps, w_steps = args.landmarks, args.visible, args.steps, args.warmup
+    dims = 3 * n + 10
+    elem = 4 if args.cov_dtype == "float32" else 8
+
+    # ---- untimed: filter, bootstrap through observe(), resident detections --
+    flt = EKF(INIT_POSE, max_landmarks=n, max_visible=m, cov_dtype=args.cov_dtype,
+              cov_kernel=args.cov_kernel, device=dev)
+    stream = SyntheticStream(n, m, seed=rank)
+    for ids, poses in stream.bootstrap():
+        flt.observe(ids, poses)
+    total = w_steps + 2 * k_steps
+    frames = list(stream.steady(total))
+    idx_all = torch.tensor(np.stack([f[0] for f in frames]), dtype=torch.int32, device=dev)
+    z_all = torch.tensor(np.stack([f[1][:, :3] for f in frames]), dtype=torch.float64, device=dev)
+    traj = torch.zeros((total, 7), dtype=torch.float64, device=dev)
+    hip = flt.backend
+    hip.sync()
+
+    def run(lo, hi):
+        hip.observe_sequence(idx_all[lo:hi], z_all[lo:hi], traj[lo:hi])
+
+    run(0, w_steps)
+    hip.sync()
+
+    # ---- timed region: exactly K steps ---------------------------------------
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(w_steps, w_steps + k_steps)
+    hip.sync()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- final gather of trajectory + map (once per run, RCCL over xGMI) ------
+    state = torch.as_tensor(hip.get_state(), device=dev)
+    diag = torch.as_tensor(hip.get_cov_diag(), device=dev)
+    map_t = torch.cat([state[10:].reshape(n, 3), diag[10:].reshape(n, 3)], dim=1).contiguous()
+    traj_timed = traj[w_steps:w_steps + k_steps].contiguous()
+    gather_ms = 0.0
+    if dist is not None:
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        all_traj = torch.empty((world, k_steps, 7), dtype=torch.float64, device=dev)
+        all_map = torch.empty((world, n, 6), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(all_traj, traj_timed)
+        dist.all_gather_into_tensor(all_map, map_t)
+        torch.cuda.synchronize()
+        gather_ms = 1e3 * (time.perf_counter() - g0)
+        finite = bool(torch.isfinite(all_traj).all() and torch.isfinite(all_map).all())
+    else:
+        finite = bool(torch.isfinite(traj_timed).all() and torch.isfinite(map_t).all())
+
+    # ---- instrumented repeat: per-kernel HIP-event timing on the filter stream -
+    hip.set_kernel_timing(True)
+    run(w_steps + k_steps, total)
+    timing = hip.kernel_timing()
+    hip.set_kernel_timing(False)
+    cov_us, cov_launches = timing["cov_update"]
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    algo_bytes = 2.0 * dims * dims * elem                       # read P once, write once
+    achieved = algo_bytes / (cov_us * 1e-6) / 1e9 if cov_us > 0 else 0.0
+    traffic = None
+    pmc = REPO / "profiles" / "cov_update_pmc_traffic.json"
+    if pmc.exists():
+        try:
+            traffic = json.loads(pmc.read_text()).get(f"n{n}_m{m}_{args.cov_dtype}")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "EKF updates/sec at n=1024 landmarks, m=32 obs/frame" if (n, m) == (1024, 32)
+                  else f"EKF updates/sec at n={n} landmarks, m={m} obs/frame",
+        "value": world * k_steps / elapsed,
+        "unit": "updates/s",
+        "n_gpus": world, "steps": k_steps, "warmup": w_steps,
+        "ms_per_step": 1e3 * elapsed / k_steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32 covariance / f64 state" if elem == 4 else "f64",
+        "data": "synthetic",
+        "config": {"workload": f"n={n} landmarks, m={m} visible/frame, N={dims}, k={3 * m}, "
+                               f"{args.cov_dtype} covariance, one independent sequence per GPU",
+                   "sequences": world, "cov_kernel": args.cov_kernel},
+        "roofline": {"bound": "hbm", "kernel": "ekf_cov_update (P <- P + Q - W^T W)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": algo_bytes,
+                     "mean_launch_us": cov_us, "launches_timed": cov_launches,
+                     "flops_per_launch": 2.0 * dims * dims * 3 * m,
+                     "achieved_tflops": 2.0 * dims * dims * 3 * m / (cov_us * 1e-6) / 1e12
+                     if cov_us > 0 else 0.0},
+        "kernel_us": {name: round(us, 3) for name, (us, _) in timing.items()},
+        "gather_ms": gather_ms,
+        "outputs_finite": finite,
+    }
+    if world == 1 and args.cpu_frames > 0:
+        base, cpu_cams = cpu_baseline(n, m, args.cpu_frames)
+        out["cpu_baseline"] = base
+        gpu_cams = traj[:args.cpu_frames].cpu().numpy() if args.cpu_frames <= total else None
+        if gpu_cams is not None:
+            d = gpu_cams - cpu_cams
+            out["trajectory_l2_vs_cpu"] = float(np.sqrt((d[:, :3] ** 2).sum(axis=1)).max())
+            out["trajectory_rel_vs_cpu"] = float(np.abs(d).max() / max(1.0, np.abs(cpu_cams).max()))
+            out["trajectory_frames_compared"] = int(args.cpu_frames)
+        out["speedup_vs_cpu_baseline"] = out["value"] / base["value"]
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,151 @@
+/*
+ * ekf_slam_hip.h -- C ABI of the MI355X (gfx950) EKF-SLAM update path.
+ *
+ * Drop-in boundary for the reference filter back-end
+ *   /root/reference/filters/extended_kalman_filter.py  (class EKF)
+ * as it is driven by
+ *   /root/reference/filters/base_filter.py:203-207  (observe, get_poses)
+ *   /root/reference/filters/base_filter.py:214-247  (save_map getters)
+ *
+ * Plain C, no torch / C++ types.  Every function returns 0 (EKF_OK) or a
+ * negative error code; ekf_last_error_string() describes the last failure on
+ * the calling thread.  A filter handle has exactly one caller thread; all
+ * device work is enqueued on the handle's HIP stream; observe calls return
+ * before the GPU has finished, getters synchronise.
+ *
+ * Memory: the covariance, state and workspace live in DEVICE memory owned by
+ * the caller (the Python shim passes torch tensor data_ptr()s).  The library
+ * never allocates or frees them; they must outlive the handle.
+ *
+ * State layout (extended_kalman_filter.py:29-34,46-51):
+ *   state  f64 [3 n + 10] = [x y z | qw qx qy qz | ex ey ez | l0 | l1 | ...]
+ *   cov    f32 or f64, row-major, leading dimension `ld` (capacity-padded to a
+ *          multiple of 128; rows/cols >= 3 n + 10 are kept exactly zero)
+ */
+#ifndef EKF_SLAM_HIP_H
+#define EKF_SLAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ekf_filter ekf_filter; /* opaque handle */
+
+enum { EKF_COV_F64 = 0, EKF_COV_F32 = 1 };
+/* camera quaternion injection (extended_kalman_filter.py:138-149):
+ * AS_WRITTEN reproduces the reference exactly (scalar-first arrays passed to
+ * SciPy's scalar-last from_quat); SCALAR_FIRST is the consistent convention
+ * (what ekf_with_rotations.py:150-151 does). */
+enum { EKF_QUAT_AS_WRITTEN = 0, EKF_QUAT_SCALAR_FIRST = 1 };
+/* covariance-update kernel selection (0 = best available) */
+enum { EKF_COVK_AUTO = 0, EKF_COVK_VALU = 1, EKF_COVK_MFMA = 2 };
+
+enum {
+    EKF_OK = 0,
+    EKF_ERR_INVALID = -1,   /* bad argument */
+    EKF_ERR_CAPACITY = -2,  /* more landmarks / observations than configured */
+    EKF_ERR_HIP = -3,       /* a HIP runtime call failed */
+    EKF_ERR_STATE = -4,     /* buffers not bound, filter not reset, ... */
+    EKF_ERR_NUMERIC = -5    /* innovation covariance not positive definite */
+};
+
+typedef struct ekf_config {
+    int32_t max_landmarks;  /* capacity n_max */
+    int32_t max_visible;    /* max observations per frame (<= 64) */
+    int32_t cov_dtype;      /* EKF_COV_F64 / EKF_COV_F32 */
+    int32_t quat_mode;      /* EKF_QUAT_* */
+    int32_t cov_kernel;     /* EKF_COVK_* */
+    int32_t reserved;
+    /* noise constants, defaults = extended_kalman_filter.py:21-27 */
+    double initial_camera_uncertainty;   /* 0.1  */
+    double initial_landmark_uncertainty; /* 0.7  */
+    double r_uncertainty;                /* 0.9  */
+    double q_cam;                        /* 0.3  */
+    double q_err;                        /* 0.5  */
+    double q_lm;                         /* 0.01 */
+    void *stream;                        /* hipStream_t, NULL = default */
+} ekf_config;
+
+/* Fill `cfg` with the reference's constants (extended_kalman_filter.py:19-34). */
+int ekf_default_config(ekf_config *cfg);
+
+/* Sizes of the caller-owned device buffers for this configuration. */
+int ekf_query_sizes(const ekf_config *cfg, int64_t *ld, size_t *cov_bytes,
+                    size_t *state_bytes, size_t *workspace_bytes);
+
+/* EKF.__init__ (extended_kalman_filter.py:40-56) without the SymPy step. */
+int ekf_create(const ekf_config *cfg, ekf_filter **out);
+int ekf_destroy(ekf_filter *f);
+
+/* Borrow caller-owned device memory (see ekf_query_sizes). */
+int ekf_bind_buffers(ekf_filter *f, void *cov_dev, int64_t ld, double *state_dev,
+                     void *workspace_dev, size_t workspace_bytes);
+
+/* state = initial pose, P = 0.1 I_10, no landmarks
+ * (extended_kalman_filter.py:46-51). */
+int ekf_reset(ekf_filter *f, const double initial_camera_pose[10]);
+
+/* EKF.add_marker for `count` new landmarks (extended_kalman_filter.py:239-290):
+ * t_ml = R(q)^-1 * cam_frame_xyz + cam_xyz with the CURRENT camera state,
+ * appended to the state; P grows by diag(diag_uncertainty) (or 0.7 I if NULL).
+ * Host pointers: cam_frame_xyz [count,3], diag_uncertainty [count,3] or NULL.
+ * The new landmarks get indices n .. n+count-1 (the marker-id -> index dict
+ * stays on the Python side). */
+int ekf_add_markers(ekf_filter *f, const double *cam_frame_xyz,
+                    const double *diag_uncertainty, int32_t count);
+
+/* EKF.predict + EKF.update for one frame (extended_kalman_filter.py:95-156):
+ * lm_index [m] = landmark indices of the visible markers in `ids` order
+ * (duplicates legal), z [m,3] = pose[0:3] of every detection.
+ * ekf_observe takes host pointers (copied during the call);
+ * ekf_observe_device takes device pointers that must stay valid until the
+ * stream has consumed them. */
+int ekf_observe(ekf_filter *f, const int32_t *lm_index, const double *z, int32_t m);
+int ekf_observe_device(ekf_filter *f, const int32_t *lm_index_dev,
+                       const double *z_dev, int32_t m);
+
+/* `frames` consecutive observe() calls on device-resident detections
+ * lm_index_dev [frames,m], z_dev [frames,m,3]; after every frame the camera
+ * pose state[0:7] is appended to trajectory_dev [frames,7] (may be NULL). */
+int ekf_observe_sequence_device(ekf_filter *f, const int32_t *lm_index_dev,
+                                const double *z_dev, int32_t m, int32_t frames,
+                                double *trajectory_dev);
+
+/* EKF.get_poses / get_lm_uncertainties (extended_kalman_filter.py:84-93).
+ * Synchronise the stream and copy to host. */
+int ekf_get_camera(ekf_filter *f, double out[10]);
+int ekf_get_state(ekf_filter *f, double *out, int32_t count);
+int ekf_get_cov_diag(ekf_filter *f, double *out, int32_t count);
+/* Full covariance as host f64 [dims,dims] (tests, checkpointing). */
+int ekf_get_cov(ekf_filter *f, double *out, int32_t dims);
+
+/* Restore (state, P) from host f64 (map restore / teacher-forced tests).
+ * cov is [dims,dims] with dims = 3*num_landmarks+10; it is symmetrised
+ * ((P+P^T)/2) on upload. */
+int ekf_set_state(ekf_filter *f, const double *state, int32_t num_landmarks);
+int ekf_set_cov(ekf_filter *f, const double *cov, int32_t dims);
+
+int ekf_num_landmarks(const ekf_filter *f);
+int ekf_sync(ekf_filter *f);
+
+/* Per-kernel device timing with HIP events on the handle's stream.
+ * which: 0 gather, 1 solve, 2 panel, 3 covariance update.
+ * ekf_get_kernel_timing synchronises, returns the mean duration [us] and the
+ * launch count since the last enable, then clears the accumulated events. */
+int ekf_set_kernel_timing(ekf_filter *f, int32_t enable);
+int ekf_get_kernel_timing(ekf_filter *f, int32_t which, double *mean_us, int64_t *launches);
+
+/* Last frame's intermediates as host f64 (tests): what = 0 Jacobian blocks
+ * [k,13], 1 residual [k], 2 Cholesky factor L [kpad,kpad], 3 whitened panel
+ * W = L^-1 H P [kpad,dims], 4 A = H (P+Q) [k,dims].  `count` = capacity of out. */
+int ekf_debug_fetch(ekf_filter *f, int32_t what, double *out, size_t count);
+
+const char *ekf_last_error_string(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EKF_SLAM_HIP_H */
