@@ -90,6 +90,7 @@ struct ekf_filter {
     ekf_config cfg{};
     Layout lay{};
     hipStream_t stream = nullptr;
+    int device = 0;
     void* cov = nullptr;
     int64_t ld = 0;
     double* state = nullptr;
@@ -199,6 +200,7 @@ int check_ready(ekf_filter* f) {
     if (!f) return fail(EKF_ERR_INVALID, "filter handle is NULL");
     if (!f->bound) return fail(EKF_ERR_STATE, "ekf_bind_buffers has not been called");
     if (!f->is_reset) return fail(EKF_ERR_STATE, "ekf_reset has not been called");
+    HIP_TRY(hipSetDevice(f->device));
     return EKF_OK;
 }
 
@@ -255,6 +257,7 @@ int ekf_create(const ekf_config* cfg, ekf_filter** out) {
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (ndev < 1) return fail(EKF_ERR_HIP, "no HIP device visible");
     ekf_filter* f = new ekf_filter();
+    if (hipGetDevice(&f->device) != hipSuccess) f->device = 0;   // the caller's current device
     f->cfg = *cfg;
     f->lay = make_layout(*cfg);
     f->stream = static_cast<hipStream_t>(cfg->stream);
@@ -310,6 +313,7 @@ int ekf_reset(ekf_filter* f, const double initial_camera_pose[10]) {
     if (!f) return fail(EKF_ERR_INVALID, "filter handle is NULL");
     if (!f->bound) return fail(EKF_ERR_STATE, "ekf_bind_buffers has not been called");
     if (!initial_camera_pose) return fail(EKF_ERR_INVALID, "initial pose is NULL");
+    HIP_TRY(hipSetDevice(f->device));
     const Layout& L = f->lay;
     HIP_TRY(hipStreamSynchronize(f->stream));
     HIP_TRY(hipMemsetAsync(f->cov, 0, (size_t)L.cap * L.cap * L.elem, f->stream));

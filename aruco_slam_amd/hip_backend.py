@@ -58,6 +58,10 @@ def load_library(path: str | Path | None = None):
         raise FileNotFoundError(
             f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback for the EKF update path)")
+    # torch ships its own libamdhip64.so.7 (same SONAME as /opt/rocm's).  Import
+    # torch FIRST so the library below binds to that already-loaded runtime: a
+    # second HIP runtime in the process sees no device.
+    import torch  # noqa: F401
     lib = C.CDLL(str(p))
     dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p
     sig = {
