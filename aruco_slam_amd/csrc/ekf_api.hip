@@ -39,7 +39,7 @@ struct Layout {
     int64_t cap;      // padded state dimension (multiple of 128)
     int kmax;         // 3 * max_visible rounded up to 16
     size_t elem;      // sizeof(cov element)
-    size_t off_jac, off_resid, off_y, off_lmcol, off_amat, off_lmat, off_dinv, off_wpanel, off_wdbg,
+    size_t off_jac, off_resid, off_y, off_lmcol, off_amat, off_lmat, off_dinv, off_lop, off_dop, off_wpanel, off_wdbg,
         off_idx, off_z, off_status, off_diag, off_xyz, off_unc, total;
 };
 
@@ -57,6 +57,11 @@ Layout make_layout(const ekf_config& c) {
     L.off_amat = take((size_t)L.kmax * L.cap * 8);
     L.off_lmat = take((size_t)L.kmax * L.kmax * 8);
     L.off_dinv = take((size_t)L.kmax * EKF_RB * 8);
+    {
+        const size_t nb = (size_t)L.kmax / EKF_RB;
+        L.off_lop = take(nb * (nb - 1) / 2 * 256 * 8 + 256);
+        L.off_dop = take(nb * 256 * 8);
+    }
     L.off_wpanel = take((size_t)L.kmax * L.cap * L.elem);
     L.off_wdbg = take((size_t)L.kmax * L.cap * 8);
     L.off_idx = take((size_t)c.max_visible * 4);
@@ -80,6 +85,8 @@ int check_config(const ekf_config* c) {
         return fail(EKF_ERR_INVALID, "unknown quat_mode");
     if (c->cov_kernel < EKF_COVK_AUTO || c->cov_kernel > EKF_COVK_MFMA)
         return fail(EKF_ERR_INVALID, "unknown cov_kernel");
+    if (c->panel_kernel < EKF_COVK_AUTO || c->panel_kernel > EKF_COVK_MFMA)
+        return fail(EKF_ERR_INVALID, "unknown panel_kernel");
     if (!(c->r_uncertainty > 0.0)) return fail(EKF_ERR_INVALID, "r_uncertainty must be > 0");
     return EKF_OK;
 }
@@ -155,6 +162,8 @@ EkfFrame make_frame(ekf_filter* f, const int32_t* idx_dev, const double* z_dev, 
     fr.lmat = f->at<double>(L.off_lmat);
     fr.ldl = L.kmax;
     fr.dinv = f->at<double>(L.off_dinv);
+    fr.lop = f->at<double>(L.off_lop);
+    fr.dop = f->at<double>(L.off_dop);
     fr.yvec = f->at<double>(L.off_y);
     fr.wpanel = f->at<void>(L.off_wpanel);
     fr.ldw = L.cap;
@@ -186,7 +195,9 @@ int enqueue_frame(ekf_filter* f, const int32_t* idx_dev, const double* z_dev, in
     if (ev) HIP_TRY(hipEventRecord(ev[1], f->stream));
     ekf_launch_solve(fr, f->stream);
     if (ev) HIP_TRY(hipEventRecord(ev[2], f->stream));
-    if (f32) ekf_launch_panel<float>(fr, f->stream); else ekf_launch_panel<double>(fr, f->stream);
+    const int pvariant = f->cfg.panel_kernel == EKF_COVK_VALU ? 1 : 2;
+    if (f32) ekf_launch_panel<float>(fr, pvariant, f->stream);
+    else ekf_launch_panel<double>(fr, pvariant, f->stream);
     if (ev) HIP_TRY(hipEventRecord(ev[3], f->stream));
     if (f32) ekf_launch_cov_update<float>(fr, variant, f->stream);
     else ekf_launch_cov_update<double>(fr, variant, f->stream);

@@ -11,16 +11,20 @@
 // Bitwise symmetry: element (i,j) and (j,i) run the same k-ordered fma chain
 // on commuting products, so P stays exactly symmetric.
 //
-//  * VALU kernel  : plain LDS-tiled reference implementation (any T).
-//  * MFMA f32     : v_mfma_f32_32x32x2_f32, 128x128 tile / 4 waves, each wave a
-//                   32 x 128 slab = four 32x32 accumulators that share the A
-//                   operand.  Column c of sub-tile t is tile column 4c+t, so a
-//                   lane's four accumulators of one row are 16 contiguous
-//                   bytes of P (dwordx4 loads/stores) and its four B operands
-//                   are one ds_read_b128.
-//  * MFMA f64     : v_mfma_f64_16x16x4_f64, 128x64 tile / 4 waves, each wave
-//                   32 x 64 = 2x4 accumulators; column c of sub-tile t is tile
-//                   column 32(t>>1) + 2c + (t&1)  (16-byte accesses again).
+//  * VALU kernel : plain LDS-tiled reference implementation (any T), computes
+//                  every tile of the full matrix.
+//  * MFMA kernels: one wavefront per 32x32 tile of the LOWER triangle (I >= J).
+//                  No LDS staging and no barriers: the k-major W panel is tiny
+//                  (k x N) and L2 resident, so each lane pulls its two operands
+//                  per MFMA straight from it; the wave needs 16 (f32) / 32
+//                  (f64) accumulator registers, so 8 / 4 waves per SIMD are
+//                  resident and the hardware overlaps one wave's P traffic with
+//                  other waves' matrix work.  An off-diagonal tile is computed
+//                  once and written twice: D to (I,J) and, transposed through a
+//                  wave-private LDS tile, D^T to (J,I).  Flops are halved
+//                  (N^2 k), P is read once per lower tile and written once.
+//                  f32: v_mfma_f32_32x32x2_f32, one accumulator.
+//                  f64: v_mfma_f64_16x16x4_f64, 2x2 accumulators.
 #include "ekf_kernels.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -78,161 +82,162 @@ __global__ __launch_bounds__(256) void ekf_cov_update_valu(EkfFrame fr) {
 }
 
 // --------------------------------------------------------------------------
-// MFMA f32: 128x128 tile, K chunks of 32 through LDS
+// tile index -> (I, J), I >= J, row-major over the lower triangle
 // --------------------------------------------------------------------------
-#define F32_KC 32
-__global__ __launch_bounds__(256, 2) void ekf_cov_update_mfma_f32(EkfFrame fr) {
-    __shared__ __attribute__((aligned(16))) float sA[F32_KC][128];
-    __shared__ __attribute__((aligned(16))) float sB[F32_KC][128];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+__device__ __forceinline__ void ekf_tri_decode(int item, int& I, int& J) {
+    int i = (int)((sqrtf(8.0f * (float)item + 1.0f) - 1.0f) * 0.5f);
+    while (i * (i + 1) / 2 > item) --i;
+    while ((i + 1) * (i + 2) / 2 <= item) ++i;
+    I = i;
+    J = item - i * (i + 1) / 2;
+}
+
+// --------------------------------------------------------------------------
+// MFMA f32: one wave per 32x32 lower tile
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ekf_cov_update_mfma_f32(EkfFrame fr, int nitems) {
+    __shared__ float tr[4][32][33];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int i0 = blockIdx.y * 128, j0 = blockIdx.x * 128;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= nitems) return;                       // wave-uniform, no barriers below
+    int I, J;
+    ekf_tri_decode(item, I, J);
+    const int i0 = 32 * I, j0 = 32 * J;
     const float* __restrict__ wp = static_cast<const float*>(fr.wpanel);
     float* __restrict__ P = static_cast<float*>(fr.cov);
     const int64_t ld = fr.ld, ldw = fr.ldw;
 
-    // P slab of this wave: rows i0+32*wave+rowmap(reg,lhi), 16 B per lane per row
-    float4 pt[16];
+    // C/D layout of 32x32x2: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    float pt[16];
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
-        const int row = i0 + 32 * wave + (reg & 3) + 8 * (reg >> 2) + 4 * lhi;
-        pt[reg] = *reinterpret_cast<const float4*>(P + (int64_t)row * ld + j0 + 4 * l31);
+        const int row = i0 + (reg & 3) + 8 * (reg >> 2) + 4 * lhi;
+        pt[reg] = P[(int64_t)row * ld + j0 + l31];
     }
-    f32x16 acc[4];
+    f32x16 acc;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    // A[i = l31][k = lhi] = -W[k][i0 + l31],  B[k = lhi][j = l31] = W[k][j0 + l31]
+    const float* wa = wp + (int64_t)lhi * ldw + i0 + l31;
+    const float* wb = wp + (int64_t)lhi * ldw + j0 + l31;
+    const int steps = fr.kpad >> 1;                   // kpad is a multiple of 16
+    for (int kk = 0; kk < steps; kk += 8) {
+        float a[8], b[8];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-
-    for (int kc = 0; kc < fr.kpad; kc += F32_KC) {
-        // stage W[kc:kc+32][i0:i0+128] and [j0:j0+128]; 4 float4 per thread per panel
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int e = tid + 256 * t, r = e >> 5, c4 = e & 31;
-            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
-            if (kc + r < fr.kpad) {
-                va = *reinterpret_cast<const float4*>(wp + (int64_t)(kc + r) * ldw + i0 + 4 * c4);
-                vb = *reinterpret_cast<const float4*>(wp + (int64_t)(kc + r) * ldw + j0 + 4 * c4);
-            }
-            *reinterpret_cast<float4*>(&sA[r][4 * c4]) = va;
-            *reinterpret_cast<float4*>(&sB[r][4 * c4]) = vb;
+        for (int u = 0; u < 8; ++u) {
+            a[u] = wa[(int64_t)(2 * (kk + u)) * ldw];
+            b[u] = wb[(int64_t)(2 * (kk + u)) * ldw];
         }
-        __syncthreads();
 #pragma unroll
-        for (int kk = 0; kk < F32_KC / 2; ++kk) {
-            // A[i = l31][k = lhi] = -W[k][i0 + 32 wave + l31];  B[k = lhi][j = l31] = W[k][j0 + 4 l31 + t]
-            const float a = -sA[2 * kk + lhi][32 * wave + l31];
-            const float4 b = *reinterpret_cast<const float4*>(&sB[2 * kk + lhi][4 * l31]);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.x, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.y, acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.z, acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.w, acc[3], 0, 0, 0);
-        }
-        __syncthreads();
+        for (int u = 0; u < 8; ++u)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-a[u], b[u], acc, 0, 0, 0);
     }
+    float out[16];
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
-        const int row = i0 + 32 * wave + (reg & 3) + 8 * (reg >> 2) + 4 * lhi;
-        const int col = j0 + 4 * l31;
-        float4 v = pt[reg];
-        if (row >= col && row < col + 4) {
-            const float q = (float)ekf_qdiag(row, fr.dims, fr.nz);
-            if (row == col) v.x += q;
-            else if (row == col + 1) v.y += q;
-            else if (row == col + 2) v.z += q;
-            else v.w += q;
+        const int rl = (reg & 3) + 8 * (reg >> 2) + 4 * lhi;
+        float v = pt[reg];
+        if (I == J && rl == l31) v += (float)ekf_qdiag(i0 + rl, fr.dims, fr.nz);
+        v += acc[reg];
+        out[reg] = v;
+        P[(int64_t)(i0 + rl) * ld + j0 + l31] = v;
+    }
+    if (I != J) {
+        // mirror: D^T -> tile (J, I), transposed through wave-private LDS
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+            tr[wave][(reg & 3) + 8 * (reg >> 2) + 4 * lhi][l31] = out[reg];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int c = 2 * it + lhi;               // column of D = row of D^T
+            P[(int64_t)(j0 + c) * ld + i0 + l31] = tr[wave][l31][c];
         }
-        v.x += acc[0][reg];
-        v.y += acc[1][reg];
-        v.z += acc[2][reg];
-        v.w += acc[3][reg];
-        *reinterpret_cast<float4*>(P + (int64_t)row * ld + col) = v;
     }
 }
 
 // --------------------------------------------------------------------------
-// MFMA f64: 128 (rows) x 64 (cols) tile, K chunks of 16 through LDS
+// MFMA f64: one wave per 32x32 lower tile = 2x2 tiles of 16x16x4
 // --------------------------------------------------------------------------
-#define F64_KC 16
-__global__ __launch_bounds__(256, 2) void ekf_cov_update_mfma_f64(EkfFrame fr) {
-    __shared__ __attribute__((aligned(16))) double sA[F64_KC][128];
-    __shared__ __attribute__((aligned(16))) double sB[F64_KC][64];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int l15 = lane & 15, lg = lane >> 4;
-    const int i0 = blockIdx.y * 128, j0 = blockIdx.x * 64;
+__global__ __launch_bounds__(256) void ekf_cov_update_mfma_f64(EkfFrame fr, int nitems) {
+    __shared__ double tr[4][32][33];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = lane & 15, g = lane >> 4;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= nitems) return;
+    int I, J;
+    ekf_tri_decode(item, I, J);
+    const int i0 = 32 * I, j0 = 32 * J;
     const double* __restrict__ wp = static_cast<const double*>(fr.wpanel);
     double* __restrict__ P = static_cast<double*>(fr.cov);
     const int64_t ld = fr.ld, ldw = fr.ldw;
 
-    double2 pt[2][4][2];
+    // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 reg
+    double pt[2][2][4];
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int ri = 0; ri < 2; ++ri)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int row = i0 + 32 * wave + 16 * rb + lg + 4 * reg;
+        for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
-                pt[rb][reg][p] = *reinterpret_cast<const double2*>(
-                    P + (int64_t)row * ld + j0 + 32 * p + 2 * l15);
+            for (int r = 0; r < 4; ++r)
+                pt[ri][ci][r] = P[(int64_t)(i0 + 16 * ri + g + 4 * r) * ld + j0 + 16 * ci + c];
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[ri][ci][r] = 0.0;
+    // A[i = c][k = g] = -W[k][i0 + 16 ri + c],  B[k = g][j = c] = W[k][j0 + 16 ci + c]
+    const double* wa = wp + (int64_t)g * ldw + i0 + c;
+    const double* wb = wp + (int64_t)g * ldw + j0 + c;
+    const int steps = fr.kpad >> 2;                   // multiple of 4
+    for (int ks = 0; ks < steps; ks += 4) {
+        double a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t off = (int64_t)(4 * (ks + u)) * ldw;
+            a0[u] = wa[off];
+            a1[u] = wa[off + 16];
+            b0[u] = wb[off];
+            b1[u] = wb[off + 16];
         }
-    f64x4 acc[2][4];
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[rb][t][r] = 0.0;
-
-    for (int kc = 0; kc < fr.kpad; kc += F64_KC) {   // kpad is a multiple of 16
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {                // sA: 16 x 128 doubles = 1024 double2
-            const int e = tid + 256 * t, r = e >> 6, c2 = e & 63;
-            *reinterpret_cast<double2*>(&sA[r][2 * c2]) =
-                *reinterpret_cast<const double2*>(wp + (int64_t)(kc + r) * ldw + i0 + 2 * c2);
+        for (int u = 0; u < 4; ++u) {
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0[u], b0[u], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0[u], b1[u], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1[u], b0[u], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1[u], b1[u], acc[1][1], 0, 0, 0);
         }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {                // sB: 16 x 64 doubles = 512 double2
-            const int e = tid + 256 * t, r = e >> 5, c2 = e & 31;
-            *reinterpret_cast<double2*>(&sB[r][2 * c2]) =
-                *reinterpret_cast<const double2*>(wp + (int64_t)(kc + r) * ldw + j0 + 2 * c2);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < F64_KC / 4; ++ks) {
-            const int kr = 4 * ks + lg;
-            // A[i = l15][k = lg] = -W[k][i0 + 32 wave + 16 rb + l15]
-            const double a0 = -sA[kr][32 * wave + l15];
-            const double a1 = -sA[kr][32 * wave + 16 + l15];
-            // B[k = lg][j = l15] = W[k][j0 + 32 (t>>1) + 2 l15 + (t&1)]
-            const double2 b01 = *reinterpret_cast<const double2*>(&sB[kr][2 * l15]);
-            const double2 b23 = *reinterpret_cast<const double2*>(&sB[kr][32 + 2 * l15]);
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b01.x, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b01.y, acc[0][1], 0, 0, 0);
-            acc[0][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b23.x, acc[0][2], 0, 0, 0);
-            acc[0][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b23.y, acc[0][3], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b01.x, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b01.y, acc[1][1], 0, 0, 0);
-            acc[1][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b23.x, acc[1][2], 0, 0, 0);
-            acc[1][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b23.y, acc[1][3], 0, 0, 0);
-        }
-        __syncthreads();
     }
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int ri = 0; ri < 2; ++ri)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int row = i0 + 32 * wave + 16 * rb + lg + 4 * reg;   // f64 C/D: row = (lane>>4) + 4 reg
+        for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int col = j0 + 32 * p + 2 * l15;
-                double2 v = pt[rb][reg][p];
-                if (row == col) v.x += ekf_qdiag(row, fr.dims, fr.nz);
-                else if (row == col + 1) v.y += ekf_qdiag(row, fr.dims, fr.nz);
-                v.x += acc[rb][2 * p][reg];
-                v.y += acc[rb][2 * p + 1][reg];
-                *reinterpret_cast<double2*>(P + (int64_t)row * ld + col) = v;
+            for (int r = 0; r < 4; ++r) {
+                const int rl = 16 * ri + g + 4 * r, cl = 16 * ci + c;
+                double v = pt[ri][ci][r];
+                if (I == J && rl == cl) v += ekf_qdiag(i0 + rl, fr.dims, fr.nz);
+                v += acc[ri][ci][r];
+                P[(int64_t)(i0 + rl) * ld + j0 + cl] = v;
+                if (I != J) tr[wave][rl][cl] = v;
             }
+    if (I != J) {
+        __builtin_amdgcn_wave_barrier();
+        const int l31 = lane & 31, lhi = lane >> 5;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int cc = 2 * it + lhi;
+            P[(int64_t)(j0 + cc) * ld + i0 + l31] = tr[wave][l31][cc];
         }
+    }
+}
+
+static inline int ekf_tri_items(const EkfFrame& fr) {
+    const int t = (fr.dims + 31) / 32;                // 32 t <= ncols <= ld
+    return t * (t + 1) / 2;
 }
 
 template <>
@@ -241,8 +246,8 @@ void ekf_launch_cov_update<float>(const EkfFrame& fr, int variant, hipStream_t s
         hipLaunchKernelGGL(ekf_cov_update_valu<float>, dim3(fr.ncols / 64, fr.ncols / 64), dim3(256),
                            0, s, fr);
     } else {
-        hipLaunchKernelGGL(ekf_cov_update_mfma_f32, dim3(fr.ncols / 128, fr.ncols / 128), dim3(256),
-                           0, s, fr);
+        const int items = ekf_tri_items(fr);
+        hipLaunchKernelGGL(ekf_cov_update_mfma_f32, dim3((items + 3) / 4), dim3(256), 0, s, fr, items);
     }
 }
 template <>
@@ -251,7 +256,7 @@ void ekf_launch_cov_update<double>(const EkfFrame& fr, int variant, hipStream_t 
         hipLaunchKernelGGL(ekf_cov_update_valu<double>, dim3(fr.ncols / 64, fr.ncols / 64),
                            dim3(256), 0, s, fr);
     } else {
-        hipLaunchKernelGGL(ekf_cov_update_mfma_f64, dim3(fr.ncols / 64, fr.ncols / 128), dim3(256),
-                           0, s, fr);
+        const int items = ekf_tri_items(fr);
+        hipLaunchKernelGGL(ekf_cov_update_mfma_f64, dim3((items + 3) / 4), dim3(256), 0, s, fr, items);
     }
 }

@@ -24,6 +24,12 @@ struct EkfFrame {
     double* lmat;          // Cholesky factor L of S, [kmax, ldl] f64 (lower)
     int32_t ldl;
     double* dinv;          // inverse of the 16x16 diagonal blocks of L, [kmax/16,16,16]
+    // the same factor pre-arranged as v_mfma_f64_16x16x4 A operands (one
+    // coalesced 512-byte read per MFMA in the panel kernel):
+    //   lop[((b(b-1)/2 + q) 4 + r) 64 + lane] = -L[16b + (lane&15)][16q + (lane>>4) + 4r], q < b
+    //   dop[(4 b + r) 64 + lane]             = Dinv_b[lane&15][(lane>>4) + 4r]
+    double* lop;
+    double* dop;
     double* yvec;          // L^-1 (z - h), [kmax]
     void* wpanel;          // W = L^-1 A, [kmax, ldw], cov dtype, k-major
     int64_t ldw;
@@ -36,7 +42,8 @@ struct EkfFrame {
 
 template <typename T> void ekf_launch_gather(const EkfFrame& fr, hipStream_t s);
 void ekf_launch_solve(const EkfFrame& fr, hipStream_t s);
-template <typename T> void ekf_launch_panel(const EkfFrame& fr, hipStream_t s);
+// variant: 1 = VALU reference kernel, 2 = MFMA kernel
+template <typename T> void ekf_launch_panel(const EkfFrame& fr, int variant, hipStream_t s);
 // P <- P + Q - W^T W.  variant: 1 = VALU reference kernel, 2 = MFMA kernel.
 template <typename T> void ekf_launch_cov_update(const EkfFrame& fr, int variant, hipStream_t s);
 

@@ -154,9 +154,212 @@ __global__ __launch_bounds__(256) void ekf_solve_kernel(EkfFrame fr) {
             x[i] = (i < jc) ? 0.0 : ((i == jc) ? inv : -sacc * inv);
         }
 #pragma unroll
-        for (int i = 0; i < EKF_RB; ++i) fr.dinv[(size_t)(r0 + i) * EKF_RB + jc] = x[i];
+        for (int i = 0; i < EKF_RB; ++i) {
+            fr.dinv[(size_t)(r0 + i) * EKF_RB + jc] = x[i];
+            fr.dop[(size_t)(b * 4 + (jc >> 2)) * 64 + i + 16 * (jc & 3)] = x[i];
+        }
+    }
+    {   // -L blocks in MFMA A-operand order
+        const int nb = kp / EKF_RB;
+        const int total = nb * (nb - 1) / 2 * 256;
+        for (int e = tid; e < total; e += 256) {
+            const int lane = e & 63, r = (e >> 6) & 3, bq = e >> 8;
+            int b = 1;
+            while ((b + 1) * b / 2 <= bq) ++b;            // bq = b(b-1)/2 + q, q < b
+            const int q = bq - b * (b - 1) / 2;
+            fr.lop[e] = -SP(16 * b + (lane & 15), 16 * q + (lane >> 4) + 4 * r);
+        }
     }
 #undef SP
+}
+
+// --------------------------------------------------------------------------
+// solve, fast path (kpad <= 128): blocked left-looking Cholesky, S dense in LDS.
+//   phase 1  all waves : block column b -= L[:, <b] L[b, <b]^T   (v_mfma_f64_16x16x4)
+//   phase 2  wave 0    : 16 pivots on up to 64 rows at once, lane = row, the 16
+//                        panel entries of a row in registers, pivot row broadcast
+//                        by v_readlane (no LDS, no barrier inside the chain)
+//   phase 3  waves 1-3 : rows beyond wave 0's 64: in-lane triangular solve
+// The residual rides along as row kp, so its factor row is y = L^-1 (z - h).
+// --------------------------------------------------------------------------
+typedef double sf64x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double ekf_readlane_f64(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double ekf_rsqrt_f64(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double e = __builtin_fma(-h * y, y, 0.5);
+        y = __builtin_fma(y, e, y);
+    }
+    return y;
+}
+
+int ekf_solve_blocked_lds_bytes(int kpad, int k) {
+    const size_t ldd = (size_t)kpad + 2;
+    return (int)((((size_t)kpad + 1) * ldd + (size_t)k * EKF_JCOLS + (size_t)k * EKF_CAM + kpad + 2) *
+                 sizeof(double));
+}
+
+__global__ __launch_bounds__(256) void ekf_solve_blocked_kernel(EkfFrame fr) {
+    extern __shared__ __attribute__((aligned(16))) double b_sm[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c = lane & 15, g = lane >> 4;
+    const int k = fr.k, kp = fr.kpad, nb = kp / EKF_RB, LD = kp + 2, m = fr.m;
+    double* S = b_sm;                                   // [kp + 1][LD], row kp = residual
+    double* invd = S + (size_t)(kp + 1) * LD;           // [kp]  1 / L_jj
+    double* hl = invd + kp + (kp & 1);                  // [k][13]
+    double* ac = hl + (size_t)k * EKF_JCOLS;            // [k][10]  A[:, 0:10]
+
+    for (int e = tid; e < k * EKF_JCOLS; e += 256)
+        hl[e] = fr.jac[(size_t)(e / EKF_JCOLS) * EKF_JLD + (e % EKF_JCOLS)];
+    for (int e = tid; e < k * EKF_CAM; e += 256)
+        ac[e] = fr.amat[(int64_t)(e / EKF_CAM) * fr.lda + (e % EKF_CAM)];
+    for (int e = tid; e < (kp + 1) * LD; e += 256) S[e] = 0.0;
+    __syncthreads();
+    // S = A[:, support] H^T + R (lower); pairs (row r1, detection jp) -> 3 entries
+    for (int p = tid; p < k * m; p += 256) {
+        const int r1 = p / m, jp = p - r1 * m;
+        if (3 * jp > r1) continue;
+        const int c0 = fr.lmcol[jp];
+        const double* ar = fr.amat + (int64_t)r1 * fr.lda + c0;
+        const double al0 = ar[0], al1 = ar[1], al2 = ar[2];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int r2 = 3 * jp + d;
+            if (r2 <= r1) {
+                const double* h2 = hl + r2 * EKF_JCOLS;
+                double acc = (r1 == r2) ? fr.nz.r_unc : 0.0;
+#pragma unroll
+                for (int bb = 0; bb < EKF_CAM; ++bb) acc += ac[r1 * EKF_CAM + bb] * h2[bb];
+                acc += al0 * h2[10] + al1 * h2[11] + al2 * h2[12];
+                S[r1 * LD + r2] = acc;
+            }
+        }
+    }
+    for (int r = k + tid; r < kp; r += 256) S[r * LD + r] = 1.0;       // identity padding
+    for (int j = tid; j < k; j += 256) S[kp * LD + j] = fr.resid[j];    // augmented row
+    __syncthreads();
+
+    int bad = 0;
+    for (int b = 0; b < nb; ++b) {
+        const int cb = EKF_RB * b;
+        if (b > 0) {
+            // ---- phase 1: row blocks b .. nb (nb = residual row), round-robin over waves
+            for (int i = b + wave; i <= nb; i += 4) {
+                const int rbase = EKF_RB * i;
+                const int arow = min(rbase + c, kp);              // residual block: all rows alias kp
+                sf64x4 t;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t[r] = S[min(rbase + g + 4 * r, kp) * LD + cb + c];
+                for (int q = 0; q < b; ++q) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int kc = EKF_RB * q + g + 4 * r;
+                        const double av = -S[arow * LD + kc];     // A[i = c][k = g + 4r]
+                        const double bv = S[(cb + c) * LD + kc];  // B[k][j = c] = L[cb + c][k]
+                        t = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, t, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rbase + g + 4 * r;
+                    if (row <= kp) S[row * LD + cb + c] = t[r];
+                }
+            }
+            __syncthreads();
+        }
+        // ---- phase 2: wave 0, lane = row cb + lane
+        const int last_w0 = min(cb + 63, kp);
+        if (wave == 0) {
+            const int row = cb + lane;
+            const bool valid = row <= kp;
+            const double* src = S + (size_t)min(row, kp) * LD + cb;
+            double a[EKF_RB];
+#pragma unroll
+            for (int x = 0; x < EKF_RB; ++x) a[x] = src[x];
+#pragma unroll
+            for (int j = 0; j < EKF_RB; ++j) {
+                const double d = ekf_readlane_f64(a[j], j);
+                bad |= !(d > 0.0);
+                const double y = ekf_rsqrt_f64(d);
+                const double lj = a[j] * y;
+                a[j] = lj;
+                if (lane == 0) invd[cb + j] = y;
+#pragma unroll
+                for (int x = j + 1; x < EKF_RB; ++x) {
+                    const double lx = ekf_readlane_f64(lj, x);
+                    a[x] = __builtin_fma(-lj, lx, a[x]);
+                }
+            }
+            if (valid) {
+                double* dst = S + (size_t)row * LD + cb;
+#pragma unroll
+                for (int x = 0; x < EKF_RB; ++x) dst[x] = a[x];
+            }
+        }
+        __syncthreads();
+        // ---- phase 3: rows below wave 0's window
+        if (last_w0 < kp) {
+            const int row = cb + 64 + (tid - 64);
+            if (wave > 0 && row <= kp) {
+                double* rp = S + (size_t)row * LD + cb;
+                double x[EKF_RB];
+#pragma unroll
+                for (int j = 0; j < EKF_RB; ++j) {
+                    double acc = rp[j];
+#pragma unroll
+                    for (int q = 0; q < j; ++q) acc = __builtin_fma(-x[q], S[(cb + j) * LD + cb + q], acc);
+                    x[j] = acc * invd[cb + j];
+                }
+#pragma unroll
+                for (int j = 0; j < EKF_RB; ++j) rp[j] = x[j];
+            }
+            __syncthreads();
+        }
+    }
+    if (bad && lane == 0) atomicOr(fr.status, 1);
+
+    // ---- outputs: y, dense L (debug / tests), -L in MFMA operand order, Dinv
+    for (int j = tid; j < kp; j += 256) fr.yvec[j] = S[kp * LD + j];
+    for (int e = tid; e < kp * kp; e += 256) {
+        const int i = e / kp, j = e - i * kp;
+        fr.lmat[(size_t)i * fr.ldl + j] = (j <= i) ? S[i * LD + j] : 0.0;
+    }
+    {
+        const int total = nb * (nb - 1) / 2 * 256;
+        for (int e = tid; e < total; e += 256) {
+            const int ln = e & 63, r = (e >> 6) & 3, bq = e >> 8;
+            int b = 1;
+            while ((b + 1) * b / 2 <= bq) ++b;
+            const int q = bq - b * (b - 1) / 2;
+            fr.lop[e] = -S[(16 * b + (ln & 15)) * LD + 16 * q + (ln >> 4) + 4 * r];
+        }
+    }
+    if (tid < kp) {
+        const int b = tid >> 4, jc = tid & 15, r0 = b * EKF_RB;
+        double x[EKF_RB];
+#pragma unroll
+        for (int i = 0; i < EKF_RB; ++i) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < EKF_RB; ++cc)
+                if (cc >= jc && cc < i) sacc += S[(r0 + i) * LD + r0 + cc] * x[cc];
+            const double inv = invd[r0 + i];
+            x[i] = (i < jc) ? 0.0 : ((i == jc) ? inv : -sacc * inv);
+        }
+#pragma unroll
+        for (int i = 0; i < EKF_RB; ++i) {
+            fr.dinv[(size_t)(r0 + i) * EKF_RB + jc] = x[i];
+            fr.dop[(size_t)(b * 4 + (jc >> 2)) * 64 + i + 16 * (jc & 3)] = x[i];
+        }
+    }
 }
 
 void ekf_launch_solve(const EkfFrame& fr, hipStream_t s) {
@@ -164,9 +367,15 @@ void ekf_launch_solve(const EkfFrame& fr, hipStream_t s) {
     if (!once) {   // > 64 KB of dynamic LDS needs the opt-in
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ekf_solve_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ekf_solve_blocked_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         once = true;
     }
-    hipLaunchKernelGGL(ekf_solve_kernel, dim3(1), dim3(256), ekf_solve_lds_bytes(fr.kpad), s, fr);
+    if (fr.kpad <= 128)
+        hipLaunchKernelGGL(ekf_solve_blocked_kernel, dim3(1), dim3(256),
+                           ekf_solve_blocked_lds_bytes(fr.kpad, fr.k), s, fr);
+    else
+        hipLaunchKernelGGL(ekf_solve_kernel, dim3(1), dim3(256), ekf_solve_lds_bytes(fr.kpad), s, fr);
 }
 
 // --------------------------------------------------------------------------
@@ -258,8 +467,102 @@ __global__ __launch_bounds__(256) void ekf_panel_kernel(EkfFrame fr) {
     }
 }
 
+typedef double pf64x4 __attribute__((ext_vector_type(4)));
+
+// MFMA panel kernel: one wave per 16 columns, everything in registers.
+// Block row b:  T = A_b - sum_{q<b} L_bq W_q ;  W_b = Dinv_b T.
+// W_q sits in the accumulator layout (lane (g,j), reg r <-> row g+4r, col j),
+// which IS the B-operand layout of MFMA step r when step r sums over the rows
+// {g+4r}; lop/dop hold the A operands in exactly that k order.
+template <typename T, int NB>
+__global__ __launch_bounds__(64) void ekf_panel_mfma_kernel(EkfFrame fr) {
+    const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
+    const int col0 = blockIdx.x * 16;
+    const double* __restrict__ lop = fr.lop;
+    const double* __restrict__ dop = fr.dop;
+    pf64x4 w[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        pf64x4 t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            t[r] = fr.amat[(int64_t)(16 * b + g + 4 * r) * fr.lda + col0 + j];
+#pragma unroll
+        for (int q = 0; q < b; ++q) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double a = lop[(size_t)((b * (b - 1) / 2 + q) * 4 + r) * 64 + lane];
+                t = __builtin_amdgcn_mfma_f64_16x16x4f64(a, w[q][r], t, 0, 0, 0);
+            }
+        }
+        pf64x4 wb = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double a = dop[(size_t)(b * 4 + r) * 64 + lane];
+            wb = __builtin_amdgcn_mfma_f64_16x16x4f64(a, t[r], wb, 0, 0, 0);
+        }
+        w[b] = wb;
+    }
+    T* __restrict__ wp = static_cast<T*>(fr.wpanel);
+    double part = 0.0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * b + g + 4 * r;
+            const double v = w[b][r];
+            part += v * fr.yvec[row];
+            wp[(int64_t)row * fr.ldw + col0 + j] = (T)v;
+            if (fr.wdbg) fr.wdbg[(int64_t)row * fr.ldw + col0 + j] = v;
+        }
+    part += __shfl_xor(part, 16);
+    part += __shfl_xor(part, 32);                    // dx[col0 + j] in every lane group
+    const int col = col0 + j;
+    double nv = 0.0;
+    if (g == 0 && (col < 3 || (col >= EKF_CAM && col < fr.dims))) {
+        nv = fr.state[col] + part;                   // extended_kalman_filter.py:134-135
+        fr.state[col] = nv;
+    }
+    if (blockIdx.x == 0) {
+        const double e0 = __shfl(part, 7), e1 = __shfl(part, 8), e2 = __shfl(part, 9);
+        const double x0 = __shfl(nv, 0), x1 = __shfl(nv, 1), x2 = __shfl(nv, 2);
+        if (lane == 0) {
+            double q[4] = {fr.state[3], fr.state[4], fr.state[5], fr.state[6]};
+            const double err[3] = {e0, e1, e2};
+            ekf_quat_inject(q, err, fr.quat_mode);
+            for (int i = 0; i < 4; ++i) fr.state[3 + i] = q[i];
+            for (int i = 0; i < 3; ++i) fr.state[7 + i] = 0.0;   // :152
+            if (fr.traj_row) {
+                fr.traj_row[0] = x0; fr.traj_row[1] = x1; fr.traj_row[2] = x2;
+                for (int i = 0; i < 4; ++i) fr.traj_row[3 + i] = q[i];
+            }
+        }
+    }
+}
+
+template <typename T, int NB>
+static void ekf_panel_mfma_go(const EkfFrame& fr, hipStream_t s) {
+    hipLaunchKernelGGL((ekf_panel_mfma_kernel<T, NB>), dim3(fr.ncols / 16), dim3(64), 0, s, fr);
+}
+
 template <typename T>
-void ekf_launch_panel(const EkfFrame& fr, hipStream_t s) {
+void ekf_launch_panel(const EkfFrame& fr, int variant, hipStream_t s) {
+    if (variant != 1) {
+        switch (fr.kpad / EKF_RB) {
+            case 1: return ekf_panel_mfma_go<T, 1>(fr, s);
+            case 2: return ekf_panel_mfma_go<T, 2>(fr, s);
+            case 3: return ekf_panel_mfma_go<T, 3>(fr, s);
+            case 4: return ekf_panel_mfma_go<T, 4>(fr, s);
+            case 5: return ekf_panel_mfma_go<T, 5>(fr, s);
+            case 6: return ekf_panel_mfma_go<T, 6>(fr, s);
+            case 7: return ekf_panel_mfma_go<T, 7>(fr, s);
+            case 8: return ekf_panel_mfma_go<T, 8>(fr, s);
+            case 9: return ekf_panel_mfma_go<T, 9>(fr, s);
+            case 10: return ekf_panel_mfma_go<T, 10>(fr, s);
+            case 11: return ekf_panel_mfma_go<T, 11>(fr, s);
+            default: return ekf_panel_mfma_go<T, 12>(fr, s);
+        }
+    }
     static bool once = false;
     if (!once) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ekf_panel_kernel<T>),
@@ -269,8 +572,8 @@ void ekf_launch_panel(const EkfFrame& fr, hipStream_t s) {
     hipLaunchKernelGGL(ekf_panel_kernel<T>, dim3(fr.ncols / 32), dim3(256),
                        ekf_panel_lds_bytes(fr.kpad), s, fr);
 }
-template void ekf_launch_panel<float>(const EkfFrame&, hipStream_t);
-template void ekf_launch_panel<double>(const EkfFrame&, hipStream_t);
+template void ekf_launch_panel<float>(const EkfFrame&, int, hipStream_t);
+template void ekf_launch_panel<double>(const EkfFrame&, int, hipStream_t);
 
 // --------------------------------------------------------------------------
 // add_marker (extended_kalman_filter.py:239-290), one thread per new landmark

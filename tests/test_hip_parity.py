@@ -100,13 +100,14 @@ def test_g2_teacher_forced_vs_reference(dtype):
 
 @pytest.mark.parametrize("dtype,kernel", [("float64", "mfma"), ("float64", "valu"),
                                           ("float32", "mfma"), ("float32", "valu")])
-def test_c1_teacher_forced_chain_all_200_frames(dtype, kernel):
+def test_c1_teacher_forced_chain_all_200_frames(dtype, kernel):  # kernel: both panel and cov
     """Every frame of the C1 replay as a single step from the oracle's prior:
     no chaos amplification, so the per-step bound holds on all 200 frames."""
     det = load_npz("c1_detections.npz")
     offs = det["offsets"]
     orc = _oracle(mode="fast")
-    flt = _ekf(max_landmarks=16, max_visible=8, cov_dtype=dtype, cov_kernel=kernel)
+    flt = _ekf(max_landmarks=16, max_visible=8, cov_dtype=dtype, cov_kernel=kernel,
+               panel_kernel=kernel)
     worst_s = worst_p = 0.0
     for f in range(len(det["timestamps_ms"])):
         if not det["has_detections"][f]:
@@ -208,12 +209,15 @@ def test_g4_scale_vs_reference(name, dtype, tol):
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_mfma_and_valu_kernels_agree_bitwise(dtype):
-    """Both covariance kernels run the same k-ordered fma chain."""
+    """Both covariance kernels run the same k-ordered fma chain (the symmetric
+    MFMA kernel computes the lower triangle and mirrors it; the VALU kernel
+    computes every element)."""
     from aruco_slam_amd.synthetic import SyntheticStream
     res = []
     for kernel in ("valu", "mfma"):
         s = SyntheticStream(96, 12, seed=5)
-        flt = _ekf(max_landmarks=96, max_visible=12, cov_dtype=dtype, cov_kernel=kernel)
+        flt = _ekf(max_landmarks=96, max_visible=12, cov_dtype=dtype, cov_kernel=kernel,
+                   panel_kernel="mfma")
         for ids, poses in list(s.bootstrap()) + list(s.steady(3)):
             flt.observe(ids, poses)
         res.append((flt.state, flt.uncertainty))
