@@ -39,8 +39,8 @@ struct Layout {
     int64_t cap;      // padded state dimension (multiple of 128)
     int kmax;         // 3 * max_visible rounded up to 16
     size_t elem;      // sizeof(cov element)
-    size_t off_jac, off_resid, off_y, off_lmcol, off_amat, off_lmat, off_dinv, off_lop, off_dop, off_wpanel, off_wdbg,
-        off_idx, off_z, off_status, off_diag, off_xyz, off_unc, total;
+    size_t off_jac, off_resid, off_y, off_lmcol, off_amat, off_asup, off_lmat, off_dinv, off_lop, off_dop, off_wpanel, off_wdbg,
+        off_idx, off_z, off_status, off_stamps, off_diag, off_xyz, off_unc, total;
 };
 
 Layout make_layout(const ekf_config& c) {
@@ -55,6 +55,7 @@ Layout make_layout(const ekf_config& c) {
     L.off_y = take((size_t)L.kmax * 8);
     L.off_lmcol = take((size_t)c.max_visible * 4);
     L.off_amat = take((size_t)L.kmax * L.cap * 8);
+    L.off_asup = take((size_t)L.kmax * (L.kmax + 2) * 8);
     L.off_lmat = take((size_t)L.kmax * L.kmax * 8);
     L.off_dinv = take((size_t)L.kmax * EKF_RB * 8);
     {
@@ -67,6 +68,7 @@ Layout make_layout(const ekf_config& c) {
     L.off_idx = take((size_t)c.max_visible * 4);
     L.off_z = take((size_t)c.max_visible * 3 * 8);
     L.off_status = take(256);
+    L.off_stamps = take(64 * 8);
     L.off_diag = take((size_t)L.cap * 8);
     L.off_xyz = take((size_t)256 * 3 * 8);
     L.off_unc = take((size_t)256 * 3 * 8);
@@ -85,8 +87,6 @@ int check_config(const ekf_config* c) {
         return fail(EKF_ERR_INVALID, "unknown quat_mode");
     if (c->cov_kernel < EKF_COVK_AUTO || c->cov_kernel > EKF_COVK_MFMA)
         return fail(EKF_ERR_INVALID, "unknown cov_kernel");
-    if (c->panel_kernel < EKF_COVK_AUTO || c->panel_kernel > EKF_COVK_MFMA)
-        return fail(EKF_ERR_INVALID, "unknown panel_kernel");
     if (!(c->r_uncertainty > 0.0)) return fail(EKF_ERR_INVALID, "r_uncertainty must be > 0");
     return EKF_OK;
 }
@@ -159,6 +159,8 @@ EkfFrame make_frame(ekf_filter* f, const int32_t* idx_dev, const double* z_dev, 
     fr.lmcol = f->at<int32_t>(L.off_lmcol);
     fr.amat = f->at<double>(L.off_amat);
     fr.lda = L.cap;
+    fr.asup = f->at<double>(L.off_asup);
+    fr.ldas = fr.kpad + 2;              // = the solve kernel's LDS row stride
     fr.lmat = f->at<double>(L.off_lmat);
     fr.ldl = L.kmax;
     fr.dinv = f->at<double>(L.off_dinv);
@@ -170,6 +172,7 @@ EkfFrame make_frame(ekf_filter* f, const int32_t* idx_dev, const double* z_dev, 
     fr.wdbg = f->debug_w ? f->at<double>(L.off_wdbg) : nullptr;
     fr.status = f->at<int32_t>(L.off_status);
     fr.traj_row = traj_row;
+    fr.stamps = f->debug_w ? f->at<long long>(L.off_stamps) : nullptr;
     fr.nz = EkfNoise{f->cfg.q_cam, f->cfg.q_err, f->cfg.q_lm, f->cfg.r_uncertainty};
     fr.quat_mode = f->cfg.quat_mode;
     return fr;
@@ -195,9 +198,7 @@ int enqueue_frame(ekf_filter* f, const int32_t* idx_dev, const double* z_dev, in
     if (ev) HIP_TRY(hipEventRecord(ev[1], f->stream));
     ekf_launch_solve(fr, f->stream);
     if (ev) HIP_TRY(hipEventRecord(ev[2], f->stream));
-    const int pvariant = f->cfg.panel_kernel == EKF_COVK_VALU ? 1 : 2;
-    if (f32) ekf_launch_panel<float>(fr, pvariant, f->stream);
-    else ekf_launch_panel<double>(fr, pvariant, f->stream);
+    if (f32) ekf_launch_panel<float>(fr, f->stream); else ekf_launch_panel<double>(fr, f->stream);
     if (ev) HIP_TRY(hipEventRecord(ev[3], f->stream));
     if (f32) ekf_launch_cov_update<float>(fr, variant, f->stream);
     else ekf_launch_cov_update<double>(fr, variant, f->stream);
@@ -594,6 +595,14 @@ int ekf_debug_fetch(ekf_filter* f, int32_t what, double* out, size_t count) {
             if (count < (size_t)k * dims) return fail(EKF_ERR_INVALID, "out too small");
             HIP_TRY(hipMemcpy2D(out, (size_t)dims * 8, f->at<double>(L.off_amat), (size_t)L.cap * 8,
                                 (size_t)dims * 8, k, hipMemcpyDeviceToHost));
+            return EKF_OK;
+        case 5:
+            if (count < 64) return fail(EKF_ERR_INVALID, "out too small");
+            {
+                long long st[64];
+                HIP_TRY(hipMemcpy(st, f->at<long long>(L.off_stamps), sizeof(st), hipMemcpyDeviceToHost));
+                for (int i = 0; i < 64; ++i) out[i] = (double)st[i];
+            }
             return EKF_OK;
         default:
             return fail(EKF_ERR_INVALID, "unknown debug item");

@@ -21,6 +21,9 @@ struct EkfFrame {
     int32_t* lmcol;        // [mmax] first state column of each detection
     double* amat;          // A = H (P+Q), [kmax, lda] f64
     int64_t lda;
+    double* asup;          // A restricted to the landmark support columns: asup[r][3 jp + e] =
+                           // A[r][lmcol[jp] + e], [kmax, ldas]  (what S = A H^T needs besides A[:,0:10])
+    int32_t ldas;
     double* lmat;          // Cholesky factor L of S, [kmax, ldl] f64 (lower)
     int32_t ldl;
     double* dinv;          // inverse of the 16x16 diagonal blocks of L, [kmax/16,16,16]
@@ -36,14 +39,14 @@ struct EkfFrame {
     double* wdbg;          // optional f64 copy of W for tests (may be null)
     int32_t* status;       // [0] != 0 -> non-SPD innovation covariance seen
     double* traj_row;      // optional: state[0:7] after the update
+    long long* stamps;     // optional: s_memtime stamps of the solve kernel's phases (diagnostics)
     EkfNoise nz;
     int32_t quat_mode;
 };
 
 template <typename T> void ekf_launch_gather(const EkfFrame& fr, hipStream_t s);
 void ekf_launch_solve(const EkfFrame& fr, hipStream_t s);
-// variant: 1 = VALU reference kernel, 2 = MFMA kernel
-template <typename T> void ekf_launch_panel(const EkfFrame& fr, int variant, hipStream_t s);
+template <typename T> void ekf_launch_panel(const EkfFrame& fr, hipStream_t s);
 // P <- P + Q - W^T W.  variant: 1 = VALU reference kernel, 2 = MFMA kernel.
 template <typename T> void ekf_launch_cov_update(const EkfFrame& fr, int variant, hipStream_t s);
 
@@ -54,4 +57,3 @@ void ekf_launch_add_markers(void* cov, int64_t ld, double* state, int32_t dims,
 template <typename T>
 void ekf_launch_cov_diag(const void* cov, int64_t ld, double* out_dev, int32_t count, hipStream_t s);
 int ekf_solve_lds_bytes(int kpad);
-int ekf_panel_lds_bytes(int kpad);

@@ -17,19 +17,40 @@
 template <typename T>
 __global__ __launch_bounds__(256) void ekf_gather_kernel(EkfFrame fr) {
     extern __shared__ __attribute__((aligned(16))) double g_sm[];
+    __shared__ int scount[64];           // support slots that live in this column chunk
+    __shared__ int sslot[64][4];
     double* hs = g_sm;                                  // [k][13]
     int* lmc = reinterpret_cast<int*>(g_sm + fr.k * EKF_JCOLS);
     const int tid = threadIdx.x;
     const int m = fr.m;
+    const int chunk0 = blockIdx.x * 64;
+    const int cl = tid & 63;
+    const int c = chunk0 + cl;                     // < ncols <= ld by construction
+    const int g = tid >> 6;                        // wave index: wave-uniform landmark
+    const T* __restrict__ P = static_cast<const T*>(fr.cov);
+    const int64_t ld = fr.ld;
+    // camera rows of P for this column: independent of the Jacobians, issue first
+    double pc[EKF_CAM];
+#pragma unroll
+    for (int a = 0; a < EKF_CAM; ++a) pc[a] = (double)P[a * ld + c];
+    if (tid < 64) scount[tid] = 0;
+    if (tid < m) lmc[tid] = EKF_CAM + EKF_LM * fr.idx[tid];
+    __syncthreads();
     if (tid < m) {
-        const int c0 = EKF_CAM + EKF_LM * fr.idx[tid];
+        const int c0 = lmc[tid];
         double cam[EKF_CAM], lm[3], h[3], J[3][EKF_JCOLS];
         for (int a = 0; a < EKF_CAM; ++a) cam[a] = fr.state[a];
         for (int d = 0; d < 3; ++d) lm[d] = fr.state[c0 + d];
         ekf_measure(cam, lm, h, J);
         for (int d = 0; d < 3; ++d)
             for (int a = 0; a < EKF_JCOLS; ++a) hs[(3 * tid + d) * EKF_JCOLS + a] = J[d][a];
-        lmc[tid] = c0;
+        for (int e = 0; e < 3; ++e) {
+            const int sl = c0 + e - chunk0;
+            if (sl >= 0 && sl < 64) {
+                const int p = atomicAdd(&scount[sl], 1);
+                if (p < 4) sslot[sl][p] = 3 * tid + e;
+            }
+        }
         if (blockIdx.x == 0) {
             for (int d = 0; d < 3; ++d) {
                 for (int a = 0; a < EKF_JCOLS; ++a)
@@ -39,34 +60,54 @@ __global__ __launch_bounds__(256) void ekf_gather_kernel(EkfFrame fr) {
             fr.lmcol[tid] = c0;
         }
     }
-    __syncthreads();
-    const int c = blockIdx.x * 64 + (tid & 63);   // < ncols <= ld by construction
-    const int g = tid >> 6;                        // wave index: wave-uniform landmark
-    const T* __restrict__ P = static_cast<const T*>(fr.cov);
-    const int64_t ld = fr.ld;
-    double pc[EKF_CAM];
 #pragma unroll
-    for (int a = 0; a < EKF_CAM; ++a) {
-        pc[a] = (double)P[a * ld + c];
+    for (int a = 0; a < EKF_CAM; ++a)
         if (a == c) pc[a] += ekf_qdiag(a, fr.dims, fr.nz);
-    }
-    for (int j = g; j < m; j += 4) {
-        const int c0 = lmc[j];
-        double pl[3];
+    // landmark rows of P for this thread's detections: also before the barrier (up to 16 per thread)
+    double plr[16][3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            pl[d] = (double)P[(int64_t)(c0 + d) * ld + c];
-            if (c0 + d == c) pl[d] += fr.nz.q_lm;
+    for (int u = 0; u < 16; ++u) {
+        const int j = g + 4 * u;
+        if (j < m) {
+            const int c0 = lmc[j];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                plr[u][d] = (double)P[(int64_t)(c0 + d) * ld + c];
+                if (c0 + d == c) plr[u][d] += fr.nz.q_lm;
+            }
         }
+    }
+    __syncthreads();
+    const int nslot = scount[cl];
+    int slots[4];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const double* hr = hs + (3 * j + d) * EKF_JCOLS;
-            double acc = 0.0;
+    for (int q = 0; q < 4; ++q) slots[q] = sslot[cl][q];
 #pragma unroll
-            for (int a = 0; a < EKF_CAM; ++a) acc += hr[a] * pc[a];
+    for (int u = 0; u < 16; ++u) {
+        const int j = g + 4 * u;
+        if (j < m) {
 #pragma unroll
-            for (int e = 0; e < 3; ++e) acc += hr[10 + e] * pl[e];
-            fr.amat[(int64_t)(3 * j + d) * fr.lda + c] = acc;
+            for (int d = 0; d < 3; ++d) {
+                const int r = 3 * j + d;
+                const double* hr = hs + r * EKF_JCOLS;
+                double acc = 0.0;
+#pragma unroll
+                for (int a = 0; a < EKF_CAM; ++a) acc += hr[a] * pc[a];
+#pragma unroll
+                for (int e = 0; e < 3; ++e) acc += hr[10 + e] * plr[u][e];
+                fr.amat[(int64_t)r * fr.lda + c] = acc;
+                if (nslot > 0) {
+                    if (nslot <= 4) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (q < nslot) fr.asup[(size_t)r * fr.ldas + slots[q]] = acc;
+                    } else {                       // > 4 detections of one landmark in a frame
+                        for (int jp = 0; jp < m; ++jp)
+                            for (int e = 0; e < 3; ++e)
+                                if (lmc[jp] + e == c) fr.asup[(size_t)r * fr.ldas + 3 * jp + e] = acc;
+                    }
+                }
+            }
         }
     }
     for (int r = fr.k + g; r < fr.kpad; r += 4) fr.amat[(int64_t)r * fr.lda + c] = 0.0;
@@ -203,10 +244,24 @@ __device__ __forceinline__ double ekf_rsqrt_f64(double d) {
 
 int ekf_solve_blocked_lds_bytes(int kpad, int k) {
     const size_t ldd = (size_t)kpad + 2;
-    return (int)((((size_t)kpad + 1) * ldd + (size_t)k * EKF_JCOLS + (size_t)k * EKF_CAM + kpad + 2) *
-                 sizeof(double));
+    return (int)((((size_t)kpad + 1) * ldd + (size_t)k * (EKF_CAM + EKF_JCOLS) + kpad + 4) * sizeof(double));
 }
 
+// -L blocks of block column p in MFMA operand order (see EkfFrame::lop); one wave.
+__device__ __forceinline__ void ekf_solve_emit_lop(const EkfFrame& fr, const double* S, int LD,
+                                                   int nb, int p, int lane) {
+    for (int i = p + 1; i < nb; ++i) {
+        const size_t base = (size_t)(i * (i - 1) / 2 + p) * 256;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            fr.lop[base + r * 64 + lane] =
+                -S[(EKF_RB * i + (lane & 15)) * LD + EKF_RB * p + (lane >> 4) + 4 * r];
+    }
+}
+
+// MS = 5: m <= 32 detections, MS = 6: m <= 64.  Pair p -> (row r1 = p >> MS, detection
+// jp = p & (2^MS - 1)); a thread's pairs all share jp (256 is a multiple of 2^MS).
+template <int MS>
 __global__ __launch_bounds__(256) void ekf_solve_blocked_kernel(EkfFrame fr) {
     extern __shared__ __attribute__((aligned(16))) double b_sm[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -214,38 +269,87 @@ __global__ __launch_bounds__(256) void ekf_solve_blocked_kernel(EkfFrame fr) {
     const int k = fr.k, kp = fr.kpad, nb = kp / EKF_RB, LD = kp + 2, m = fr.m;
     double* S = b_sm;                                   // [kp + 1][LD], row kp = residual
     double* invd = S + (size_t)(kp + 1) * LD;           // [kp]  1 / L_jj
-    double* hl = invd + kp + (kp & 1);                  // [k][13]
-    double* ac = hl + (size_t)k * EKF_JCOLS;            // [k][10]  A[:, 0:10]
-
-    for (int e = tid; e < k * EKF_JCOLS; e += 256)
-        hl[e] = fr.jac[(size_t)(e / EKF_JCOLS) * EKF_JLD + (e % EKF_JCOLS)];
-    for (int e = tid; e < k * EKF_CAM; e += 256)
-        ac[e] = fr.amat[(int64_t)(e / EKF_CAM) * fr.lda + (e % EKF_CAM)];
-    for (int e = tid; e < (kp + 1) * LD; e += 256) S[e] = 0.0;
-    __syncthreads();
-    // S = A[:, support] H^T + R (lower); pairs (row r1, detection jp) -> 3 entries
-    for (int p = tid; p < k * m; p += 256) {
-        const int r1 = p / m, jp = p - r1 * m;
-        if (3 * jp > r1) continue;
-        const int c0 = fr.lmcol[jp];
-        const double* ar = fr.amat + (int64_t)r1 * fr.lda + c0;
-        const double al0 = ar[0], al1 = ar[1], al2 = ar[2];
+    double* ac = invd + kp + 2;                         // [k][10]  A[:, 0:10]
+    int nstamp = 0;
+#define EKF_STAMP() do { if (fr.stamps && tid == 0) fr.stamps[nstamp] = clock64(); ++nstamp; } while (0)
+    EKF_STAMP();
+    // ---- build S = A[:, support] H^T + R (lower triangle).
+    // asup (row stride LD) is copied flat into S with coalesced 16-byte loads; entry
+    // S[r1][3jp+d] is then computed in place from S[r1][3jp..3jp+2] = asup[r1][3jp..3jp+2].
+    constexpr int RSTEP = 256 >> MS;                    // rows advanced per pair slot
+    constexpr int NPAIR = 16;                           // pair slots per batch
+    const int jp = tid & ((1 << MS) - 1);
+    const bool jvalid = jp < m;
+    double* hl = ac + (size_t)k * EKF_CAM;              // [k][13]
+    {
+        const int n16 = (k * LD) >> 1;                  // k * LD is even (LD even)
+        const double2* src = reinterpret_cast<const double2*>(fr.asup);
+        double2* dst = reinterpret_cast<double2*>(S);
+        double2 v[20];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const int r2 = 3 * jp + d;
-            if (r2 <= r1) {
-                const double* h2 = hl + r2 * EKF_JCOLS;
-                double acc = (r1 == r2) ? fr.nz.r_unc : 0.0;
+        for (int i = 0; i < 20; ++i) {
+            const int e = tid + 256 * i;
+            v[i] = (e < n16) ? src[e] : make_double2(0.0, 0.0);
+        }
+        double acv[8], hv[8];
 #pragma unroll
-                for (int bb = 0; bb < EKF_CAM; ++bb) acc += ac[r1 * EKF_CAM + bb] * h2[bb];
-                acc += al0 * h2[10] + al1 * h2[11] + al2 * h2[12];
-                S[r1 * LD + r2] = acc;
+        for (int i = 0; i < 8; ++i) {
+            const int e = tid + 256 * i, r = e >> 4, cc = e & 15;
+            acv[i] = (r < k && cc < EKF_CAM) ? fr.amat[(int64_t)r * fr.lda + cc] : 0.0;
+            hv[i] = (r < k) ? fr.jac[e] : 0.0;          // jac is [k][16], contiguous
+        }
+        const double rres = (tid < k) ? fr.resid[tid] : 0.0;
+#pragma unroll
+        for (int i = 0; i < 20; ++i) {
+            const int e = tid + 256 * i;
+            if (e < n16) dst[e] = v[i];
+        }
+        for (int e = tid + 256 * 20; e < n16; e += 256) dst[e] = src[e];   // (k * LD > 10240 doubles)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = tid + 256 * i, r = e >> 4, cc = e & 15;
+            if (r < k && cc < EKF_CAM) ac[r * EKF_CAM + cc] = acv[i];
+            if (r < k && cc < EKF_JCOLS) hl[r * EKF_JCOLS + cc] = hv[i];
+        }
+        // padding rows k..kp-1 = identity, residual row kp
+        const int tr = tid >> 4, tc = tid & 15;
+        for (int r = k + tr; r <= kp; r += 16) {
+            const int hi = (r < kp) ? (r | 15) : kp - 1;
+            for (int cc = tc; cc <= hi; cc += 16) S[r * LD + cc] = (r < kp && cc == r) ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        if (tid < k) S[kp * LD + tid] = rres;
+    }
+    double hreg[3][EKF_JCOLS];                          // this thread's 3 Jacobian rows
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int a = 0; a < EKF_JCOLS; ++a)
+            hreg[d][a] = jvalid ? hl[(3 * jp + d) * EKF_JCOLS + a] : 0.0;
+    for (int r0 = 0; r0 < k; r0 += NPAIR * RSTEP) {     // one batch for m <= 32, k <= 128
+#pragma unroll
+        for (int u = 0; u < NPAIR; ++u) {
+            const int r1 = r0 + (tid >> MS) + RSTEP * u;
+            if (jvalid && r1 < k && r1 >= 3 * jp) {
+                double* sp = S + r1 * LD + 3 * jp;
+                const double a0 = sp[0], a1 = sp[1], a2 = sp[2];
+                double a10[EKF_CAM];
+#pragma unroll
+                for (int bb = 0; bb < EKF_CAM; ++bb) a10[bb] = ac[r1 * EKF_CAM + bb];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const int r2 = 3 * jp + d;
+                    double acc = (r1 == r2) ? fr.nz.r_unc : 0.0;
+#pragma unroll
+                    for (int bb = 0; bb < EKF_CAM; ++bb) acc += a10[bb] * hreg[d][bb];
+                    acc += a0 * hreg[d][10] + a1 * hreg[d][11] + a2 * hreg[d][12];
+                    sp[d] = (r2 <= r1) ? acc : 0.0;   // strict upper part of a diagonal block = 0
+                }
             }
         }
     }
-    for (int r = k + tid; r < kp; r += 256) S[r * LD + r] = 1.0;       // identity padding
-    for (int j = tid; j < k; j += 256) S[kp * LD + j] = fr.resid[j];    // augmented row
     __syncthreads();
+    EKF_STAMP();
 
     int bad = 0;
     for (int b = 0; b < nb; ++b) {
@@ -254,18 +358,28 @@ __global__ __launch_bounds__(256) void ekf_solve_blocked_kernel(EkfFrame fr) {
             // ---- phase 1: row blocks b .. nb (nb = residual row), round-robin over waves
             for (int i = b + wave; i <= nb; i += 4) {
                 const int rbase = EKF_RB * i;
-                const int arow = min(rbase + c, kp);              // residual block: all rows alias kp
+                const double* arow = S + (size_t)min(rbase + c, kp) * LD + g;   // residual block aliases row kp
+                const double* brow = S + (size_t)(cb + c) * LD + g;
                 sf64x4 t;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) t[r] = S[min(rbase + g + 4 * r, kp) * LD + cb + c];
+                // operands of step q+1 are read from LDS while step q's MFMAs run
+                double av[4], bv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { av[r] = arow[4 * r]; bv[r] = brow[4 * r]; }
                 for (int q = 0; q < b; ++q) {
+                    double an[4], bn[4];
+                    const int qn = min(q + 1, b - 1);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int kc = EKF_RB * q + g + 4 * r;
-                        const double av = -S[arow * LD + kc];     // A[i = c][k = g + 4r]
-                        const double bv = S[(cb + c) * LD + kc];  // B[k][j = c] = L[cb + c][k]
-                        t = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, t, 0, 0, 0);
+                        an[r] = arow[EKF_RB * qn + 4 * r];   // A[i = c][k = g + 4r]
+                        bn[r] = brow[EKF_RB * qn + 4 * r];   // B[k][j = c] = L[cb + c][k]
                     }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        t = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[r], bv[r], t, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { av[r] = an[r]; bv[r] = bn[r]; }
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -275,91 +389,73 @@ __global__ __launch_bounds__(256) void ekf_solve_blocked_kernel(EkfFrame fr) {
             }
             __syncthreads();
         }
-        // ---- phase 2: wave 0, lane = row cb + lane
-        const int last_w0 = min(cb + 63, kp);
-        if (wave == 0) {
-            const int row = cb + lane;
-            const bool valid = row <= kp;
-            const double* src = S + (size_t)min(row, kp) * LD + cb;
-            double a[EKF_RB];
+        EKF_STAMP();
+        // ---- phase 2: 16 pivots, lane = row, pivot row broadcast by v_readlane.
+        //  wave 0          : rows cb .. cb+63
+        //  wave 1          : lanes 0-15 the diagonal rows again (every wave needs the pivot rows in
+        //                    its own lanes), lanes 16-31 the rows of I_16 -- the same recurrence
+        //                    turns e_i into row i of L_bb^-T, i.e. column i of Dinv_b for free --,
+        //                    lanes 32-63 rows cb+64 .. cb+95
+        //  waves 2, 3      : lanes 0-15 diagonal rows, lanes 16-63 rows cb+96+48(w-2) ..
+        const int xrow0 = (wave == 1) ? cb + 64 : cb + 96 + 48 * (wave - 2);
+        if (wave <= 1 || xrow0 <= kp) {
+            int row;
+            if (wave == 0 || lane < EKF_RB) row = cb + lane;
+            else if (wave == 1) row = (lane < 32) ? -1 : xrow0 + (lane - 32);
+            else row = xrow0 + (lane - EKF_RB);
+            const bool ident = row < 0;
+            const bool store = !ident && (wave == 0 || lane >= EKF_RB) && row <= kp;
+            const double* src = S + (size_t)min(max(row, 0), kp) * LD + cb;
+            double a[EKF_RB], ys[EKF_RB];
 #pragma unroll
-            for (int x = 0; x < EKF_RB; ++x) a[x] = src[x];
+            for (int x = 0; x < EKF_RB; ++x) a[x] = ident ? ((x == lane - EKF_RB) ? 1.0 : 0.0) : src[x];
 #pragma unroll
             for (int j = 0; j < EKF_RB; ++j) {
                 const double d = ekf_readlane_f64(a[j], j);
                 bad |= !(d > 0.0);
                 const double y = ekf_rsqrt_f64(d);
+                ys[j] = y;
                 const double lj = a[j] * y;
                 a[j] = lj;
-                if (lane == 0) invd[cb + j] = y;
 #pragma unroll
                 for (int x = j + 1; x < EKF_RB; ++x) {
                     const double lx = ekf_readlane_f64(lj, x);
                     a[x] = __builtin_fma(-lj, lx, a[x]);
                 }
             }
-            if (valid) {
+            if (store) {
                 double* dst = S + (size_t)row * LD + cb;
 #pragma unroll
                 for (int x = 0; x < EKF_RB; ++x) dst[x] = a[x];
             }
+            if (ident) {                                 // a[x] = Dinv_b[x][i], i = lane - 16
+                const int i = lane - EKF_RB;
+#pragma unroll
+                for (int x = 0; x < EKF_RB; ++x) {
+                    fr.dinv[(size_t)(cb + x) * EKF_RB + i] = a[x];
+                    fr.dop[(size_t)(b * 4 + (i >> 2)) * 64 + x + 16 * (i & 3)] = a[x];
+                }
+            }
+            if (tid == 0) {
+#pragma unroll
+                for (int j = 0; j < EKF_RB; ++j) invd[cb + j] = ys[j];
+            }
+        } else if (wave == 3 && b > 0) {
+            ekf_solve_emit_lop(fr, S, LD, nb, b - 1, lane);   // idle wave: operands of block column b-1
         }
         __syncthreads();
-        // ---- phase 3: rows below wave 0's window
-        if (last_w0 < kp) {
-            const int row = cb + 64 + (tid - 64);
-            if (wave > 0 && row <= kp) {
-                double* rp = S + (size_t)row * LD + cb;
-                double x[EKF_RB];
-#pragma unroll
-                for (int j = 0; j < EKF_RB; ++j) {
-                    double acc = rp[j];
-#pragma unroll
-                    for (int q = 0; q < j; ++q) acc = __builtin_fma(-x[q], S[(cb + j) * LD + cb + q], acc);
-                    x[j] = acc * invd[cb + j];
-                }
-#pragma unroll
-                for (int j = 0; j < EKF_RB; ++j) rp[j] = x[j];
-            }
-            __syncthreads();
-        }
+        EKF_STAMP();
     }
     if (bad && lane == 0) atomicOr(fr.status, 1);
-
-    // ---- outputs: y, dense L (debug / tests), -L in MFMA operand order, Dinv
+    // (block column nb-1 has no -L blocks below it)
     for (int j = tid; j < kp; j += 256) fr.yvec[j] = S[kp * LD + j];
-    for (int e = tid; e < kp * kp; e += 256) {
-        const int i = e / kp, j = e - i * kp;
-        fr.lmat[(size_t)i * fr.ldl + j] = (j <= i) ? S[i * LD + j] : 0.0;
+    if (fr.wdbg) {                                      // dense L for tests only
+        for (int i = tid >> 4; i < kp; i += 16)
+            for (int j = tid & 15; j < kp; j += 16)
+                fr.lmat[(size_t)i * fr.ldl + j] = (j <= i) ? S[i * LD + j] : 0.0;
     }
-    {
-        const int total = nb * (nb - 1) / 2 * 256;
-        for (int e = tid; e < total; e += 256) {
-            const int ln = e & 63, r = (e >> 6) & 3, bq = e >> 8;
-            int b = 1;
-            while ((b + 1) * b / 2 <= bq) ++b;
-            const int q = bq - b * (b - 1) / 2;
-            fr.lop[e] = -S[(16 * b + (ln & 15)) * LD + 16 * q + (ln >> 4) + 4 * r];
-        }
-    }
-    if (tid < kp) {
-        const int b = tid >> 4, jc = tid & 15, r0 = b * EKF_RB;
-        double x[EKF_RB];
-#pragma unroll
-        for (int i = 0; i < EKF_RB; ++i) {
-            double sacc = 0.0;
-#pragma unroll
-            for (int cc = 0; cc < EKF_RB; ++cc)
-                if (cc >= jc && cc < i) sacc += S[(r0 + i) * LD + r0 + cc] * x[cc];
-            const double inv = invd[r0 + i];
-            x[i] = (i < jc) ? 0.0 : ((i == jc) ? inv : -sacc * inv);
-        }
-#pragma unroll
-        for (int i = 0; i < EKF_RB; ++i) {
-            fr.dinv[(size_t)(r0 + i) * EKF_RB + jc] = x[i];
-            fr.dop[(size_t)(b * 4 + (jc >> 2)) * 64 + i + 16 * (jc & 3)] = x[i];
-        }
-    }
+    EKF_STAMP();
+#undef EKF_STAMP
 }
 
 void ekf_launch_solve(const EkfFrame& fr, hipStream_t s) {
@@ -367,106 +463,24 @@ void ekf_launch_solve(const EkfFrame& fr, hipStream_t s) {
     if (!once) {   // > 64 KB of dynamic LDS needs the opt-in
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ekf_solve_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ekf_solve_blocked_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ekf_solve_blocked_kernel<5>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ekf_solve_blocked_kernel<6>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         once = true;
     }
-    if (fr.kpad <= 128)
-        hipLaunchKernelGGL(ekf_solve_blocked_kernel, dim3(1), dim3(256),
-                           ekf_solve_blocked_lds_bytes(fr.kpad, fr.k), s, fr);
+    const int lds = ekf_solve_blocked_lds_bytes(fr.kpad, fr.k);
+    if (fr.kpad <= 128 && fr.m <= 32)
+        hipLaunchKernelGGL(ekf_solve_blocked_kernel<5>, dim3(1), dim3(256), lds, s, fr);
+    else if (fr.kpad <= 128)
+        hipLaunchKernelGGL(ekf_solve_blocked_kernel<6>, dim3(1), dim3(256), lds, s, fr);
     else
         hipLaunchKernelGGL(ekf_solve_kernel, dim3(1), dim3(256), ekf_solve_lds_bytes(fr.kpad), s, fr);
 }
 
 // --------------------------------------------------------------------------
-// panel: 32 columns per workgroup, blocked forward substitution with the
-// inverted diagonal blocks:  W_b = Dinv_b (A_b - sum_{q<b} L_bq W_q).
+// panel
 // --------------------------------------------------------------------------
-int ekf_panel_lds_bytes(int kpad) {
-    return (int)(((size_t)kpad * 32 + (size_t)EKF_RB * kpad + 256 + 512 + 256 + 64) * sizeof(double));
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void ekf_panel_kernel(EkfFrame fr) {
-    extern __shared__ __attribute__((aligned(16))) double p_sm[];
-    const int kp = fr.kpad;
-    double* wl = p_sm;                   // [kp][32]   A chunk, overwritten by W
-    double* lrow = wl + (size_t)kp * 32; // [16][kp]   current block row of L
-    double* dv = lrow + (size_t)EKF_RB * kp;  // [16][16]
-    double* tb = dv + 256;               // [16][32]
-    double* red = tb + 512;              // [8][32]
-    double* misc = red + 256;            // [64]
-    const int tid = threadIdx.x, c = tid & 31, g = tid >> 5;
-    const int col0 = blockIdx.x * 32;
-    for (int r = g; r < kp; r += 8) wl[r * 32 + c] = fr.amat[(int64_t)r * fr.lda + col0 + c];
-    const int nb = kp / EKF_RB;
-    for (int b = 0; b < nb; ++b) {
-        const int r0 = b * EKF_RB;
-        for (int e = tid; e < EKF_RB * r0; e += 256) {
-            const int rr = e / r0, q = e - rr * r0;
-            lrow[rr * kp + q] = fr.lmat[(size_t)(r0 + rr) * fr.ldl + q];
-        }
-        dv[tid] = fr.dinv[(size_t)b * 256 + tid];
-        __syncthreads();
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const int rr = g + 8 * hh;
-            double t = wl[(r0 + rr) * 32 + c];
-            for (int q = 0; q < r0; ++q) t -= lrow[rr * kp + q] * wl[q * 32 + c];
-            tb[rr * 32 + c] = t;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const int rr = g + 8 * hh;
-            double w = 0.0;
-            for (int i = 0; i <= rr; ++i) w += dv[rr * EKF_RB + i] * tb[i * 32 + c];
-            wl[(r0 + rr) * 32 + c] = w;
-        }
-        __syncthreads();
-    }
-    // write W (cov dtype, k-major) and dx = W^T y
-    T* __restrict__ wp = static_cast<T*>(fr.wpanel);
-    double part = 0.0;
-    for (int r = g; r < kp; r += 8) {
-        const double w = wl[r * 32 + c];
-        part += w * fr.yvec[r];
-        wp[(int64_t)r * fr.ldw + col0 + c] = (T)w;
-        if (fr.wdbg) fr.wdbg[(int64_t)r * fr.ldw + col0 + c] = w;
-    }
-    red[g * 32 + c] = part;
-    __syncthreads();
-    if (g == 0) {
-        double dx = 0.0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) dx += red[q * 32 + c];
-        const int col = col0 + c;
-        // extended_kalman_filter.py:134-135: xyz and every landmark move,
-        // delta[3:7] is dropped, delta[7:10] feeds the quaternion
-        if (col < 3 || (col >= EKF_CAM && col < fr.dims)) {
-            const double nv = fr.state[col] + dx;
-            fr.state[col] = nv;
-            if (col < 3) misc[col] = nv;
-        } else if (col >= 7 && col < EKF_CAM) {
-            misc[col] = dx;
-        }
-    }
-    if (blockIdx.x == 0) {
-        __syncthreads();
-        if (tid == 0) {
-            double q[4] = {fr.state[3], fr.state[4], fr.state[5], fr.state[6]};
-            const double err[3] = {misc[7], misc[8], misc[9]};
-            ekf_quat_inject(q, err, fr.quat_mode);
-            for (int i = 0; i < 4; ++i) fr.state[3 + i] = q[i];
-            for (int i = 0; i < 3; ++i) fr.state[7 + i] = 0.0;   // :152
-            if (fr.traj_row) {
-                for (int i = 0; i < 3; ++i) fr.traj_row[i] = misc[i];
-                for (int i = 0; i < 4; ++i) fr.traj_row[3 + i] = q[i];
-            }
-        }
-    }
-}
-
 typedef double pf64x4 __attribute__((ext_vector_type(4)));
 
 // MFMA panel kernel: one wave per 16 columns, everything in registers.
@@ -546,34 +560,24 @@ static void ekf_panel_mfma_go(const EkfFrame& fr, hipStream_t s) {
 }
 
 template <typename T>
-void ekf_launch_panel(const EkfFrame& fr, int variant, hipStream_t s) {
-    if (variant != 1) {
-        switch (fr.kpad / EKF_RB) {
-            case 1: return ekf_panel_mfma_go<T, 1>(fr, s);
-            case 2: return ekf_panel_mfma_go<T, 2>(fr, s);
-            case 3: return ekf_panel_mfma_go<T, 3>(fr, s);
-            case 4: return ekf_panel_mfma_go<T, 4>(fr, s);
-            case 5: return ekf_panel_mfma_go<T, 5>(fr, s);
-            case 6: return ekf_panel_mfma_go<T, 6>(fr, s);
-            case 7: return ekf_panel_mfma_go<T, 7>(fr, s);
-            case 8: return ekf_panel_mfma_go<T, 8>(fr, s);
-            case 9: return ekf_panel_mfma_go<T, 9>(fr, s);
-            case 10: return ekf_panel_mfma_go<T, 10>(fr, s);
-            case 11: return ekf_panel_mfma_go<T, 11>(fr, s);
-            default: return ekf_panel_mfma_go<T, 12>(fr, s);
-        }
+void ekf_launch_panel(const EkfFrame& fr, hipStream_t s) {
+    switch (fr.kpad / EKF_RB) {
+        case 1: return ekf_panel_mfma_go<T, 1>(fr, s);
+        case 2: return ekf_panel_mfma_go<T, 2>(fr, s);
+        case 3: return ekf_panel_mfma_go<T, 3>(fr, s);
+        case 4: return ekf_panel_mfma_go<T, 4>(fr, s);
+        case 5: return ekf_panel_mfma_go<T, 5>(fr, s);
+        case 6: return ekf_panel_mfma_go<T, 6>(fr, s);
+        case 7: return ekf_panel_mfma_go<T, 7>(fr, s);
+        case 8: return ekf_panel_mfma_go<T, 8>(fr, s);
+        case 9: return ekf_panel_mfma_go<T, 9>(fr, s);
+        case 10: return ekf_panel_mfma_go<T, 10>(fr, s);
+        case 11: return ekf_panel_mfma_go<T, 11>(fr, s);
+        default: return ekf_panel_mfma_go<T, 12>(fr, s);
     }
-    static bool once = false;
-    if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ekf_panel_kernel<T>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        once = true;
-    }
-    hipLaunchKernelGGL(ekf_panel_kernel<T>, dim3(fr.ncols / 32), dim3(256),
-                       ekf_panel_lds_bytes(fr.kpad), s, fr);
 }
-template void ekf_launch_panel<float>(const EkfFrame&, int, hipStream_t);
-template void ekf_launch_panel<double>(const EkfFrame&, int, hipStream_t);
+template void ekf_launch_panel<float>(const EkfFrame&, hipStream_t);
+template void ekf_launch_panel<double>(const EkfFrame&, hipStream_t);
 
 // --------------------------------------------------------------------------
 // add_marker (extended_kalman_filter.py:239-290), one thread per new landmark

@@ -58,7 +58,7 @@ typedef struct ekf_config {
     int32_t cov_dtype;      /* EKF_COV_F64 / EKF_COV_F32 */
     int32_t quat_mode;      /* EKF_QUAT_* */
     int32_t cov_kernel;     /* EKF_COVK_*: covariance-update kernel */
-    int32_t panel_kernel;   /* EKF_COVK_*: panel (W = L^-1 A) kernel */
+    int32_t reserved;
     /* noise constants, defaults = extended_kalman_filter.py:21-27 */
     double initial_camera_uncertainty;   /* 0.1  */
     double initial_landmark_uncertainty; /* 0.7  */

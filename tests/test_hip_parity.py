@@ -100,14 +100,13 @@ def test_g2_teacher_forced_vs_reference(dtype):
 
 @pytest.mark.parametrize("dtype,kernel", [("float64", "mfma"), ("float64", "valu"),
                                           ("float32", "mfma"), ("float32", "valu")])
-def test_c1_teacher_forced_chain_all_200_frames(dtype, kernel):  # kernel: both panel and cov
+def test_c1_teacher_forced_chain_all_200_frames(dtype, kernel):
     """Every frame of the C1 replay as a single step from the oracle's prior:
     no chaos amplification, so the per-step bound holds on all 200 frames."""
     det = load_npz("c1_detections.npz")
     offs = det["offsets"]
     orc = _oracle(mode="fast")
-    flt = _ekf(max_landmarks=16, max_visible=8, cov_dtype=dtype, cov_kernel=kernel,
-               panel_kernel=kernel)
+    flt = _ekf(max_landmarks=16, max_visible=8, cov_dtype=dtype, cov_kernel=kernel)
     worst_s = worst_p = 0.0
     for f in range(len(det["timestamps_ms"])):
         if not det["has_detections"][f]:
@@ -216,8 +215,7 @@ def test_mfma_and_valu_kernels_agree_bitwise(dtype):
     res = []
     for kernel in ("valu", "mfma"):
         s = SyntheticStream(96, 12, seed=5)
-        flt = _ekf(max_landmarks=96, max_visible=12, cov_dtype=dtype, cov_kernel=kernel,
-                   panel_kernel="mfma")
+        flt = _ekf(max_landmarks=96, max_visible=12, cov_dtype=dtype, cov_kernel=kernel)
         for ids, poses in list(s.bootstrap()) + list(s.steady(3)):
             flt.observe(ids, poses)
         res.append((flt.state, flt.uncertainty))

@@ -1,0 +1,17 @@
+import sys; sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+import numpy as np
+from aruco_slam_amd.filters.extended_kalman_filter import EKF
+from aruco_slam_amd.synthetic import SyntheticStream
+n,m=1024,32
+s=SyntheticStream(n,m,seed=0)
+f=EKF(np.array([0,0,0,1,0,0,0,0,0,0]),max_landmarks=n,max_visible=m,cov_dtype="float32")
+f.backend.debug_enable_w()
+for ids,p in s.bootstrap(): f.observe(ids,p)
+for ids,p in s.steady(5): f.observe(ids,p)
+st=f.backend.debug_fetch("stamps",m)
+nb=6
+d=np.diff(st[:3+2*nb])
+print("solve kernel phase stamps (shader cycles)")
+print("build", d[0])
+for b in range(nb): print("b",b,"ph1",d[1+2*b],"ph2",d[2+2*b])
+print("tail", d[1+2*nb], "total", st[2+2*nb]-st[0])
