@@ -113,6 +113,7 @@ struct ekf_filter {
     hipEvent_t slot_done[kStageSlots] = {};
     // kernel timing
     bool timing = false;
+    bool timing_cov_only = false;
     std::vector<hipEvent_t> ev;   // (kTimedKernels + 1) per frame
     int ev_frames = 0;
     double t_sum_us[kTimedKernels] = {};
@@ -128,7 +129,7 @@ int fold_timing(ekf_filter* f) {
     if (f->ev_frames == 0) return EKF_OK;
     HIP_TRY(hipStreamSynchronize(f->stream));
     for (int fr = 0; fr < f->ev_frames; ++fr) {
-        for (int kq = 0; kq < kTimedKernels; ++kq) {
+        for (int kq = f->timing_cov_only ? kTimedKernels - 1 : 0; kq < kTimedKernels; ++kq) {
             float ms = 0.f;
             HIP_TRY(hipEventElapsedTime(&ms, f->ev[fr * (kTimedKernels + 1) + kq],
                                         f->ev[fr * (kTimedKernels + 1) + kq + 1]));
@@ -192,12 +193,13 @@ int enqueue_frame(ekf_filter* f, const int32_t* idx_dev, const double* z_dev, in
         }
         ev = &f->ev[f->ev_frames * (kTimedKernels + 1)];
         f->ev_frames++;
-        HIP_TRY(hipEventRecord(ev[0], f->stream));
     }
+    hipEvent_t* ev_all = (ev && !f->timing_cov_only) ? ev : nullptr;
+    if (ev_all) HIP_TRY(hipEventRecord(ev[0], f->stream));
     if (f32) ekf_launch_gather<float>(fr, f->stream); else ekf_launch_gather<double>(fr, f->stream);
-    if (ev) HIP_TRY(hipEventRecord(ev[1], f->stream));
+    if (ev_all) HIP_TRY(hipEventRecord(ev[1], f->stream));
     ekf_launch_solve(fr, f->stream);
-    if (ev) HIP_TRY(hipEventRecord(ev[2], f->stream));
+    if (ev_all) HIP_TRY(hipEventRecord(ev[2], f->stream));
     if (f32) ekf_launch_panel<float>(fr, f->stream); else ekf_launch_panel<double>(fr, f->stream);
     if (ev) HIP_TRY(hipEventRecord(ev[3], f->stream));
     if (f32) ekf_launch_cov_update<float>(fr, variant, f->stream);
@@ -541,6 +543,7 @@ int ekf_set_kernel_timing(ekf_filter* f, int32_t enable) {
         for (auto& e : f->ev) HIP_TRY(hipEventCreate(&e));
     }
     f->timing = enable != 0;
+    f->timing_cov_only = enable == 2;
     f->ev_frames = 0;
     for (int i = 0; i < kTimedKernels; ++i) {
         f->t_sum_us[i] = 0.0;

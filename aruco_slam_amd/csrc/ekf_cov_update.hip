@@ -95,6 +95,9 @@ __device__ __forceinline__ void ekf_tri_decode(int item, int& I, int& J) {
 // --------------------------------------------------------------------------
 // MFMA f32: one wave per 32x32 lower tile
 // --------------------------------------------------------------------------
+// KB = kpad / 16: the operand stream is fully unrolled so that the compiler can put every
+// load of the W panel in flight before the first MFMA.
+template <int KB>
 __global__ __launch_bounds__(256) void ekf_cov_update_mfma_f32(EkfFrame fr, int nitems) {
     __shared__ float tr[4][32][33];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -115,23 +118,31 @@ __global__ __launch_bounds__(256) void ekf_cov_update_mfma_f32(EkfFrame fr, int 
         const int row = i0 + (reg & 3) + 8 * (reg >> 2) + 4 * lhi;
         pt[reg] = P[(int64_t)row * ld + j0 + l31];
     }
+    __builtin_amdgcn_sched_barrier(0);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     // A[i = l31][k = lhi] = -W[k][i0 + l31],  B[k = lhi][j = l31] = W[k][j0 + l31]
     const float* wa = wp + (int64_t)lhi * ldw + i0 + l31;
     const float* wb = wp + (int64_t)lhi * ldw + j0 + l31;
-    const int steps = fr.kpad >> 1;                   // kpad is a multiple of 16
-    for (int kk = 0; kk < steps; kk += 8) {
-        float a[8], b[8];
+    // super-batches of <= 48 k-pairs: every operand load of the batch (and, in the first
+    // batch, the P tile) is in flight before the first MFMA; hipcc's own schedule is
+    // load -> wait -> mfma per step, so the order is pinned with sched_barrier.
+    constexpr int SB = (KB <= 6) ? 8 * KB : 8 * ((KB + 1) / 2);     // k-pairs per super-batch
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            a[u] = wa[(int64_t)(2 * (kk + u)) * ldw];
-            b[u] = wb[(int64_t)(2 * (kk + u)) * ldw];
+    for (int k0 = 0; k0 < 8 * KB; k0 += SB) {
+        float a[SB], b[SB];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int kk = min(k0 + u, 8 * KB - 1);
+            a[u] = wa[(int64_t)(2 * kk) * ldw];
+            b[u] = wb[(int64_t)(2 * kk) * ldw];
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-a[u], b[u], acc, 0, 0, 0);
+        for (int u = 0; u < SB; ++u)
+            if (k0 + u < 8 * KB) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-a[u], b[u], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
     float out[16];
 #pragma unroll
@@ -247,7 +258,14 @@ void ekf_launch_cov_update<float>(const EkfFrame& fr, int variant, hipStream_t s
                            0, s, fr);
     } else {
         const int items = ekf_tri_items(fr);
-        hipLaunchKernelGGL(ekf_cov_update_mfma_f32, dim3((items + 3) / 4), dim3(256), 0, s, fr, items);
+        const dim3 grid((items + 3) / 4), block(256);
+        switch (fr.kpad / 16) {
+#define EKF_COV_CASE(KB) case KB: hipLaunchKernelGGL(ekf_cov_update_mfma_f32<KB>, grid, block, 0, s, fr, items); break;
+            EKF_COV_CASE(1) EKF_COV_CASE(2) EKF_COV_CASE(3) EKF_COV_CASE(4) EKF_COV_CASE(5) EKF_COV_CASE(6)
+            EKF_COV_CASE(7) EKF_COV_CASE(8) EKF_COV_CASE(9) EKF_COV_CASE(10) EKF_COV_CASE(11)
+            default: hipLaunchKernelGGL(ekf_cov_update_mfma_f32<12>, grid, block, 0, s, fr, items); break;
+#undef EKF_COV_CASE
+        }
     }
 }
 template <>

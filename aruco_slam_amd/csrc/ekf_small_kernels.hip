@@ -14,7 +14,9 @@
 // --------------------------------------------------------------------------
 // gather
 // --------------------------------------------------------------------------
-template <typename T>
+// NU = detections per wave slot (m <= 4 NU).  All loads of P are issued branch-free
+// (clamped indices) before anything consumes them.
+template <typename T, int NU>
 __global__ __launch_bounds__(256) void ekf_gather_kernel(EkfFrame fr) {
     extern __shared__ __attribute__((aligned(16))) double g_sm[];
     __shared__ int scount[64];           // support slots that live in this column chunk
@@ -29,17 +31,27 @@ __global__ __launch_bounds__(256) void ekf_gather_kernel(EkfFrame fr) {
     const int g = tid >> 6;                        // wave index: wave-uniform landmark
     const T* __restrict__ P = static_cast<const T*>(fr.cov);
     const int64_t ld = fr.ld;
-    // camera rows of P for this column: independent of the Jacobians, issue first
-    double pc[EKF_CAM];
+    // camera rows of P for this column and the camera state: independent of idx
+    T pcr[EKF_CAM];
 #pragma unroll
-    for (int a = 0; a < EKF_CAM; ++a) pc[a] = (double)P[a * ld + c];
+    for (int a = 0; a < EKF_CAM; ++a) pcr[a] = P[a * ld + c];
+    double cam[EKF_CAM];
+#pragma unroll
+    for (int a = 0; a < EKF_CAM; ++a) cam[a] = fr.state[a];
     if (tid < 64) scount[tid] = 0;
     if (tid < m) lmc[tid] = EKF_CAM + EKF_LM * fr.idx[tid];
     __syncthreads();
+    // landmark rows of P for this wave's detections
+    T plr[NU][3];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int c0 = lmc[min(g + 4 * u, m - 1)];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) plr[u][d] = P[(int64_t)(c0 + d) * ld + c];
+    }
     if (tid < m) {
         const int c0 = lmc[tid];
-        double cam[EKF_CAM], lm[3], h[3], J[3][EKF_JCOLS];
-        for (int a = 0; a < EKF_CAM; ++a) cam[a] = fr.state[a];
+        double lm[3], h[3], J[3][EKF_JCOLS];
         for (int d = 0; d < 3; ++d) lm[d] = fr.state[c0 + d];
         ekf_measure(cam, lm, h, J);
         for (int d = 0; d < 3; ++d)
@@ -60,32 +72,22 @@ __global__ __launch_bounds__(256) void ekf_gather_kernel(EkfFrame fr) {
             fr.lmcol[tid] = c0;
         }
     }
-#pragma unroll
-    for (int a = 0; a < EKF_CAM; ++a)
-        if (a == c) pc[a] += ekf_qdiag(a, fr.dims, fr.nz);
-    // landmark rows of P for this thread's detections: also before the barrier (up to 16 per thread)
-    double plr[16][3];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-        const int j = g + 4 * u;
-        if (j < m) {
-            const int c0 = lmc[j];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                plr[u][d] = (double)P[(int64_t)(c0 + d) * ld + c];
-                if (c0 + d == c) plr[u][d] += fr.nz.q_lm;
-            }
-        }
-    }
     __syncthreads();
+    double pc[EKF_CAM];
+#pragma unroll
+    for (int a = 0; a < EKF_CAM; ++a) pc[a] = (double)pcr[a] + ((a == c) ? ekf_qdiag(a, fr.dims, fr.nz) : 0.0);
     const int nslot = scount[cl];
     int slots[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) slots[q] = sslot[cl][q];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
+    for (int u = 0; u < NU; ++u) {
         const int j = g + 4 * u;
         if (j < m) {
+            const int c0 = lmc[j];
+            double pl[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) pl[d] = (double)plr[u][d] + ((c0 + d == c) ? fr.nz.q_lm : 0.0);
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
                 const int r = 3 * j + d;
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void ekf_gather_kernel(EkfFrame fr) {
 #pragma unroll
                 for (int a = 0; a < EKF_CAM; ++a) acc += hr[a] * pc[a];
 #pragma unroll
-                for (int e = 0; e < 3; ++e) acc += hr[10 + e] * plr[u][e];
+                for (int e = 0; e < 3; ++e) acc += hr[10 + e] * pl[e];
                 fr.amat[(int64_t)r * fr.lda + c] = acc;
                 if (nslot > 0) {
                     if (nslot <= 4) {
@@ -116,7 +118,10 @@ __global__ __launch_bounds__(256) void ekf_gather_kernel(EkfFrame fr) {
 template <typename T>
 void ekf_launch_gather(const EkfFrame& fr, hipStream_t s) {
     const size_t lds = (size_t)fr.k * EKF_JCOLS * sizeof(double) + (size_t)fr.m * sizeof(int) + 16;
-    hipLaunchKernelGGL(ekf_gather_kernel<T>, dim3(fr.ncols / 64), dim3(256), lds, s, fr);
+    if (fr.m <= 32)
+        hipLaunchKernelGGL((ekf_gather_kernel<T, 8>), dim3(fr.ncols / 64), dim3(256), lds, s, fr);
+    else
+        hipLaunchKernelGGL((ekf_gather_kernel<T, 16>), dim3(fr.ncols / 64), dim3(256), lds, s, fr);
 }
 template void ekf_launch_gather<float>(const EkfFrame&, hipStream_t);
 template void ekf_launch_gather<double>(const EkfFrame&, hipStream_t);
@@ -363,24 +368,29 @@ __global__ __launch_bounds__(256) void ekf_solve_blocked_kernel(EkfFrame fr) {
                 sf64x4 t;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) t[r] = S[min(rbase + g + 4 * r, kp) * LD + cb + c];
-                // operands of step q+1 are read from LDS while step q's MFMAs run
-                double av[4], bv[4];
+                sf64x4 t2 = {0.0, 0.0, 0.0, 0.0};           // second chain: halves the dependent MFMA depth
+                int q = 0;
+                for (; q + 1 < b; q += 2) {
+                    double av[8], bv[8];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { av[r] = arow[4 * r]; bv[r] = brow[4 * r]; }
-                for (int q = 0; q < b; ++q) {
-                    double an[4], bn[4];
-                    const int qn = min(q + 1, b - 1);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        an[r] = arow[EKF_RB * qn + 4 * r];   // A[i = c][k = g + 4r]
-                        bn[r] = brow[EKF_RB * qn + 4 * r];   // B[k][j = c] = L[cb + c][k]
+                    for (int r = 0; r < 8; ++r) {
+                        av[r] = arow[EKF_RB * q + 4 * r];     // A[i = c][k = g + 4r]
+                        bv[r] = brow[EKF_RB * q + 4 * r];     // B[k][j = c] = L[cb + c][k]
                     }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
+                    for (int r = 0; r < 4; ++r) {
                         t = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[r], bv[r], t, 0, 0, 0);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { av[r] = an[r]; bv[r] = bn[r]; }
+                        t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[4 + r], bv[4 + r], t2, 0, 0, 0);
+                    }
                 }
+                if (q < b) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        t = __builtin_amdgcn_mfma_f64_16x16x4f64(-arow[EKF_RB * q + 4 * r],
+                                                                 brow[EKF_RB * q + 4 * r], t, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t[r] += t2[r];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = rbase + g + 4 * r;

@@ -233,7 +233,8 @@ class HipEkf:
         self._check(self.lib.ekf_set_cov(self.h, _dptr(cov), state.shape[0]))
 
     # -- instrumentation -----------------------------------------------------
-    def set_kernel_timing(self, enable: bool):
+    def set_kernel_timing(self, enable):
+        """False/0 off, True/1 all kernels, 2 covariance update only."""
         self._check(self.lib.ekf_set_kernel_timing(self.h, int(enable)))
 
     def kernel_timing(self):

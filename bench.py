@@ -118,7 +118,7 @@ def main():
     stream = SyntheticStream(n, m, seed=rank)
     for ids, poses in stream.bootstrap():
         flt.observe(ids, poses)
-    total = w_steps + 2 * k_steps
+    total = w_steps + 3 * k_steps
     frames = list(stream.steady(total))
     idx_all = torch.tensor(np.stack([f[0] for f in frames]), dtype=torch.int32, device=dev)
     z_all = torch.tensor(np.stack([f[1][:, :3] for f in frames]), dtype=torch.float64, device=dev)
@@ -168,11 +168,15 @@ def main():
         finite = bool(torch.isfinite(traj_timed).all() and torch.isfinite(map_t).all())
 
     # ---- instrumented repeat: per-kernel HIP-event timing on the filter stream -
-    hip.set_kernel_timing(True)
-    run(w_steps + k_steps, total)
+    # pass A: the covariance-update kernel alone (2 events / frame) -> roofline
+    hip.set_kernel_timing(2)
+    run(w_steps + k_steps, w_steps + 2 * k_steps)
+    cov_us, cov_launches = hip.kernel_timing()["cov_update"]
+    # pass B: all four kernels (5 events / frame; each interval also holds a launch gap)
+    hip.set_kernel_timing(1)
+    run(w_steps + 2 * k_steps, total)
     timing = hip.kernel_timing()
-    hip.set_kernel_timing(False)
-    cov_us, cov_launches = timing["cov_update"]
+    hip.set_kernel_timing(0)
 
     if rank != 0:
         if dist is not None:

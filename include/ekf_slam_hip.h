@@ -133,6 +133,8 @@ int ekf_sync(ekf_filter *f);
 
 /* Per-kernel device timing with HIP events on the handle's stream.
  * which: 0 gather, 1 solve, 2 panel, 3 covariance update.
+ * enable: 0 off, 1 all four kernels (5 events per frame), 2 covariance update only
+ * (2 events per frame: least perturbation of the pipeline).
  * ekf_get_kernel_timing synchronises, returns the mean duration [us] and the
  * launch count since the last enable, then clears the accumulated events. */
 int ekf_set_kernel_timing(ekf_filter *f, int32_t enable);
