@@ -115,7 +115,8 @@ def main():
     # ---- untimed: filter, bootstrap through observe(), resident detections --
     flt = EKF(INIT_POSE, max_landmarks=n, max_visible=m, cov_dtype=args.cov_dtype,
               cov_kernel=args.cov_kernel, device=dev)
-    stream = SyntheticStream(n, m, seed=rank)
+    from aruco_slam_amd.sequences import rank_seed
+    stream = SyntheticStream(n, m, seed=rank_seed(0, rank))
     for ids, poses in stream.bootstrap():
         flt.observe(ids, poses)
     total = w_steps + 3 * k_steps
@@ -149,23 +150,18 @@ def main():
         elapsed = float(t.item())
 
     # ---- final gather of trajectory + map (once per run, RCCL over xGMI) ------
+    from aruco_slam_amd.sequences import gather_sequences
     state = torch.as_tensor(hip.get_state(), device=dev)
     diag = torch.as_tensor(hip.get_cov_diag(), device=dev)
     map_t = torch.cat([state[10:].reshape(n, 3), diag[10:].reshape(n, 3)], dim=1).contiguous()
     traj_timed = traj[w_steps:w_steps + k_steps].contiguous()
-    gather_ms = 0.0
-    if dist is not None:
-        torch.cuda.synchronize()
-        g0 = time.perf_counter()
-        all_traj = torch.empty((world, k_steps, 7), dtype=torch.float64, device=dev)
-        all_map = torch.empty((world, n, 6), dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(all_traj, traj_timed)
-        dist.all_gather_into_tensor(all_map, map_t)
-        torch.cuda.synchronize()
-        gather_ms = 1e3 * (time.perf_counter() - g0)
-        finite = bool(torch.isfinite(all_traj).all() and torch.isfinite(all_map).all())
-    else:
-        finite = bool(torch.isfinite(traj_timed).all() and torch.isfinite(map_t).all())
+    torch.cuda.synchronize()
+    g0 = time.perf_counter()
+    all_traj, all_map, _, _ = gather_sequences(traj_timed, map_t, dist)
+    torch.cuda.synchronize()
+    gather_ms = 1e3 * (time.perf_counter() - g0) if dist is not None else 0.0
+    finite = bool(torch.isfinite(all_traj).all() and torch.isfinite(all_map).all())
+    assert all_traj.shape == (world, k_steps, 7) and all_map.shape == (world, n, 6)
 
     # ---- instrumented repeat: per-kernel HIP-event timing on the filter stream -
     # pass A: the covariance-update kernel alone (2 events / frame) -> roofline
