@@ -181,13 +181,18 @@ def main():
 
     algo_bytes = 2.0 * dims * dims * elem                       # read P once, write once
     achieved = algo_bytes / (cov_us * 1e-6) / 1e9 if cov_us > 0 else 0.0
-    traffic = None
+    # HBM bytes per launch from rocprofv3 PMC passes (tools/profile_round.sh +
+    # tools/summarize_profile.py), and the rocprofv3 kernel-trace duration next to the
+    # HIP-event one (events bracket the launch, so they also hold the dispatch gap)
+    traffic = rocprof_us = None
     pmc = REPO / "profiles" / "cov_update_pmc_traffic.json"
     if pmc.exists():
         try:
-            traffic = json.loads(pmc.read_text()).get(f"n{n}_m{m}_{args.cov_dtype}")
+            table = json.loads(pmc.read_text())
+            traffic = table.get(f"n{n}_m{m}_{args.cov_dtype}")
+            rocprof_us = table.get(f"n{n}_m{m}_{args.cov_dtype}_rocprof_mean_us")
         except Exception:
-            traffic = None
+            traffic = rocprof_us = None
     out = {
         "metric": "EKF updates/sec at n=1024 landmarks, m=32 obs/frame" if (n, m) == (1024, 32)
                   else f"EKF updates/sec at n={n} landmarks, m={m} obs/frame",
@@ -208,6 +213,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": algo_bytes,
                      "mean_launch_us": cov_us, "launches_timed": cov_launches,
+                     "rocprofv3_mean_us": rocprof_us,
                      "flops_per_launch": 2.0 * dims * dims * 3 * m,
                      "achieved_tflops": 2.0 * dims * dims * 3 * m / (cov_us * 1e-6) / 1e12
                      if cov_us > 0 else 0.0},
