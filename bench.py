@@ -173,6 +173,15 @@ def main():
     run(w_steps + 2 * k_steps, total)
     timing = hip.kernel_timing()
     hip.set_kernel_timing(0)
+    # host-pointer boundary as BaseFilter.process_frame drives it: observe(ids, poses) with
+    # host arrays + get_poses() (device->host sync) every frame.  PCIe-inclusive; never `value`.
+    hb_frames = list(stream.steady(40))
+    flt.get_poses()
+    h0 = time.perf_counter()
+    for ids_h, poses_h in hb_frames:
+        flt.observe(ids_h, poses_h)
+        flt.get_poses()
+    host_boundary = len(hb_frames) / (time.perf_counter() - h0)
 
     if rank != 0:
         if dist is not None:
@@ -219,6 +228,7 @@ def main():
                      if cov_us > 0 else 0.0},
         "kernel_us": {name: round(us, 3) for name, (us, _) in timing.items()},
         "gather_ms": gather_ms,
+        "host_boundary_updates_per_s": host_boundary,
         "outputs_finite": finite,
     }
     if world == 1 and args.cpu_frames > 0:
