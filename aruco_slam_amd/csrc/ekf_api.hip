@@ -39,7 +39,7 @@ struct Layout {
     int64_t cap;      // padded state dimension (multiple of 128)
     int kmax;         // 3 * max_visible rounded up to 16
     size_t elem;      // sizeof(cov element)
-    size_t off_jac, off_resid, off_y, off_lmcol, off_amat, off_asup, off_lmat, off_dinv, off_lop, off_dop, off_wpanel, off_wdbg,
+    size_t off_jac, off_resid, off_y, off_lmcol, off_amat, off_asup, off_lmat, off_dinv, off_lop, off_dop, off_wpanel, off_wpanel2, off_prow, off_wdbg,
         off_idx, off_z, off_status, off_stamps, off_diag, off_xyz, off_unc, total;
 };
 
@@ -64,6 +64,8 @@ Layout make_layout(const ekf_config& c) {
         L.off_dop = take(nb * 256 * 8);
     }
     L.off_wpanel = take((size_t)L.kmax * L.cap * L.elem);
+    L.off_wpanel2 = take((size_t)L.kmax * L.cap * L.elem);
+    L.off_prow = take((size_t)(EKF_CAM + 3 * c.max_visible) * L.cap * L.elem);
     L.off_wdbg = take((size_t)L.kmax * L.cap * 8);
     L.off_idx = take((size_t)c.max_visible * 4);
     L.off_z = take((size_t)c.max_visible * 3 * 8);
@@ -97,6 +99,8 @@ struct ekf_filter {
     ekf_config cfg{};
     Layout lay{};
     hipStream_t stream = nullptr;
+    hipStream_t big = nullptr;          // internal stream: big covariance update in sequence mode
+    hipEvent_t ev_small[2] = {}, ev_big[2] = {};
     int device = 0;
     void* cov = nullptr;
     int64_t ld = 0;
@@ -283,6 +287,15 @@ int ekf_create(const ekf_config* cfg, ekf_filter** out) {
         delete f;
         return fail(EKF_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
     }
+    e = hipStreamCreateWithFlags(&f->big, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipEventCreateWithFlags(&f->ev_small[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_big[i], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+        ekf_destroy(f);
+        return fail(EKF_ERR_HIP, std::string("stream/event create: ") + hipGetErrorString(e));
+    }
     for (int i = 0; i < kStageSlots; ++i) {
         e = hipEventCreateWithFlags(&f->slot_done[i], hipEventDisableTiming);
         if (e != hipSuccess) {
@@ -297,6 +310,14 @@ int ekf_create(const ekf_config* cfg, ekf_filter** out) {
 int ekf_destroy(ekf_filter* f) {
     if (!f) return EKF_OK;
     (void)hipStreamSynchronize(f->stream);
+    if (f->big) {
+        (void)hipStreamSynchronize(f->big);
+        (void)hipStreamDestroy(f->big);
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (f->ev_small[i]) (void)hipEventDestroy(f->ev_small[i]);
+        if (f->ev_big[i]) (void)hipEventDestroy(f->ev_big[i]);
+    }
     for (auto& e : f->ev) (void)hipEventDestroy(e);
     for (int i = 0; i < kStageSlots; ++i)
         if (f->slot_done[i]) (void)hipEventDestroy(f->slot_done[i]);
@@ -432,11 +453,54 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
     if (m < 1 || frames < 0) return fail(EKF_ERR_INVALID, "bad sequence shape");
     if (m > f->cfg.max_visible) return fail(EKF_ERR_CAPACITY, "more detections than max_visible");
     if (!lm_index_dev || !z_dev) return fail(EKF_ERR_INVALID, "NULL detections");
-    for (int t = 0; t < frames; ++t) {
-        rc = enqueue_frame(f, lm_index_dev + (size_t)t * m, z_dev + (size_t)t * m * 3, m,
-                           trajectory_dev ? trajectory_dev + (size_t)t * 7 : nullptr);
-        if (rc) return rc;
+    // every cross-stream event costs a few us of bubble on the main stream, so the overlap only
+    // pays when the big update is longer than gather + solve + panel
+    const bool want = (f->cfg.flags & 2) || (!(f->cfg.flags & 1) && f->dims() >= 6144);
+    const bool lookahead = want && !f->timing && frames >= 2;
+    if (!lookahead) {
+        for (int t = 0; t < frames; ++t) {
+            rc = enqueue_frame(f, lm_index_dev + (size_t)t * m, z_dev + (size_t)t * m * 3, m,
+                               trajectory_dev ? trajectory_dev + (size_t)t * 7 : nullptr);
+            if (rc) return rc;
+        }
+        return EKF_OK;
     }
+    // Cross-frame lookahead.  Main stream: gather, solve, panel and the priority rows of every
+    // frame; internal stream: the big covariance update.  Frame t+1's gather reads its support
+    // rows of P_{t+1} from the priority-row buffer, so it only waits for frame t's small kernels.
+    const Layout& L = f->lay;
+    const bool f32 = f->cfg.cov_dtype == EKF_COV_F32;
+    const int variant = f->cfg.cov_kernel == EKF_COVK_VALU ? 1 : 2;
+    void* wbuf[2] = {f->at<void>(L.off_wpanel), f->at<void>(L.off_wpanel2)};
+    void* prow = f->at<void>(L.off_prow);
+    for (int t = 0; t < frames; ++t) {
+        const int par = t & 1;
+        EkfFrame fr = make_frame(f, lm_index_dev + (size_t)t * m, z_dev + (size_t)t * m * 3, m,
+                                 trajectory_dev ? trajectory_dev + (size_t)t * 7 : nullptr);
+        fr.wpanel = wbuf[par];
+        fr.prow = (t > 0) ? prow : nullptr;
+        if (f32) ekf_launch_gather<float>(fr, f->stream); else ekf_launch_gather<double>(fr, f->stream);
+        ekf_launch_solve(fr, f->stream);
+        if (f32) ekf_launch_panel<float>(fr, f->stream); else ekf_launch_panel<double>(fr, f->stream);
+        if (t + 1 < frames) {
+            // the rows below are read from P_t: the big update of frame t-1 must be complete
+            // (this also frees the W panel that frame t+1 will overwrite)
+            if (t > 0) HIP_TRY(hipStreamWaitEvent(f->stream, f->ev_big[(t - 1) & 1], 0));
+            fr.next_idx = lm_index_dev + (size_t)(t + 1) * m;
+            fr.next_m = m;
+            fr.prow_out = prow;
+            if (f32) ekf_launch_cov_rows<float>(fr, f->stream); else ekf_launch_cov_rows<double>(fr, f->stream);
+        }
+        HIP_TRY(hipEventRecord(f->ev_small[par], f->stream));
+        HIP_TRY(hipStreamWaitEvent(f->big, f->ev_small[par], 0));
+        if (f32) ekf_launch_cov_update<float>(fr, variant, f->big);
+        else ekf_launch_cov_update<double>(fr, variant, f->big);
+        HIP_TRY(hipEventRecord(f->ev_big[par], f->big));
+        HIP_TRY(hipGetLastError());
+    }
+    // join: everything later on the main stream (and every getter) sees the final covariance
+    HIP_TRY(hipStreamWaitEvent(f->stream, f->ev_big[(frames - 1) & 1], 0));
+    f->last_m = m;
     return EKF_OK;
 }
 

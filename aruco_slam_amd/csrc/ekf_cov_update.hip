@@ -246,6 +246,48 @@ __global__ __launch_bounds__(256) void ekf_cov_update_mfma_f64(EkfFrame fr, int 
     }
 }
 
+// --------------------------------------------------------------------------
+// Priority rows (cross-frame lookahead): the rows of the UPDATED covariance that the next frame's
+// gather reads -- camera rows 0..9 and the 3 rows of every next-frame detection -- computed
+// ahead of the big kernel into a side buffer, with exactly the per-element arithmetic of the
+// kernels above (k-ordered fma chain from zero, then P + Q + acc): bitwise what the big kernel
+// then writes into P.  grid.x = 10 + 3 next_m rows, grid.y = column chunks.
+// --------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void ekf_cov_rows_kernel(EkfFrame fr) {
+    __shared__ T wr[192];                            // -W[:, row]
+    const int slot = blockIdx.x;
+    const int row = (slot < EKF_CAM) ? slot
+                                     : EKF_CAM + EKF_LM * fr.next_idx[(slot - EKF_CAM) / 3] + (slot - EKF_CAM) % 3;
+    const T* __restrict__ wp = static_cast<const T*>(fr.wpanel);
+    const T* __restrict__ P = static_cast<const T*>(fr.cov);
+    T* __restrict__ out = static_cast<T*>(fr.prow_out);
+    for (int kk = threadIdx.x; kk < fr.kpad; kk += 256) wr[kk] = -wp[(int64_t)kk * fr.ldw + row];
+    __syncthreads();
+    const T q = (T)ekf_qdiag(row, fr.dims, fr.nz);
+    for (int col = blockIdx.y * 256 + threadIdx.x; col < fr.ncols; col += gridDim.y * 256) {
+        T v = P[(int64_t)row * fr.ld + col];
+        T acc = (T)0;
+        for (int k0 = 0; k0 < fr.kpad; k0 += 16) {   // kpad is a multiple of 16: 16 loads in flight
+            T w[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) w[u] = wp[(int64_t)(k0 + u) * fr.ldw + col];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc = __builtin_fma(wr[k0 + u], w[u], acc);
+        }
+        if (row == col) v += q;
+        out[(int64_t)slot * fr.ldw + col] = v + acc;
+    }
+}
+
+template <typename T>
+void ekf_launch_cov_rows(const EkfFrame& fr, hipStream_t s) {
+    const int chunks = (fr.ncols + 255) / 256;      // one column per thread
+    hipLaunchKernelGGL(ekf_cov_rows_kernel<T>, dim3(EKF_CAM + 3 * fr.next_m, chunks), dim3(256), 0, s, fr);
+}
+template void ekf_launch_cov_rows<float>(const EkfFrame&, hipStream_t);
+template void ekf_launch_cov_rows<double>(const EkfFrame&, hipStream_t);
+
 static inline int ekf_tri_items(const EkfFrame& fr) {
     const int t = (fr.dims + 31) / 32;                // 32 t <= ncols <= ld
     return t * (t + 1) / 2;

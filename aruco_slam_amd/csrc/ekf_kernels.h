@@ -40,6 +40,14 @@ struct EkfFrame {
     int32_t* status;       // [0] != 0 -> non-SPD innovation covariance seen
     double* traj_row;      // optional: state[0:7] after the update
     long long* stamps;     // optional: s_memtime stamps of the solve kernel's phases (diagnostics)
+    // cross-frame lookahead (sequence mode).  After the panel kernel of frame t, ekf_launch_cov_rows
+    // computes the rows of P_{t+1} that frame t+1's gather will read (camera rows 0..9 and the 3
+    // rows of every detection of frame t+1) into prow_out [10 + 3 next_m, ldw]; the gather of
+    // frame t+1 reads them from `prow` instead of P, so it no longer waits for the big update.
+    const int32_t* next_idx;   // [next_m] landmark indices of the next frame (device)
+    int32_t next_m;
+    void* prow_out;            // written by ekf_launch_cov_rows (cov dtype)
+    const void* prow;          // read by the gather kernel; null = read P
     EkfNoise nz;
     int32_t quat_mode;
 };
@@ -49,6 +57,7 @@ void ekf_launch_solve(const EkfFrame& fr, hipStream_t s);
 template <typename T> void ekf_launch_panel(const EkfFrame& fr, hipStream_t s);
 // P <- P + Q - W^T W.  variant: 1 = VALU reference kernel, 2 = MFMA kernel.
 template <typename T> void ekf_launch_cov_update(const EkfFrame& fr, int variant, hipStream_t s);
+template <typename T> void ekf_launch_cov_rows(const EkfFrame& fr, hipStream_t s);
 
 template <typename T>
 void ekf_launch_add_markers(void* cov, int64_t ld, double* state, int32_t dims,

@@ -32,9 +32,12 @@ __global__ __launch_bounds__(256) void ekf_gather_kernel(EkfFrame fr) {
     const T* __restrict__ P = static_cast<const T*>(fr.cov);
     const int64_t ld = fr.ld;
     // camera rows of P for this column and the camera state: independent of idx
+    // support rows come from P, or -- cross-frame lookahead -- from the priority-row buffer that
+    // ekf_cov_rows_kernel filled with exactly the values the covariance update is writing into P
+    const T* __restrict__ prow = static_cast<const T*>(fr.prow);
     T pcr[EKF_CAM];
 #pragma unroll
-    for (int a = 0; a < EKF_CAM; ++a) pcr[a] = P[a * ld + c];
+    for (int a = 0; a < EKF_CAM; ++a) pcr[a] = prow ? prow[(int64_t)a * fr.ldw + c] : P[a * ld + c];
     double cam[EKF_CAM];
 #pragma unroll
     for (int a = 0; a < EKF_CAM; ++a) cam[a] = fr.state[a];
@@ -45,9 +48,11 @@ __global__ __launch_bounds__(256) void ekf_gather_kernel(EkfFrame fr) {
     T plr[NU][3];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-        const int c0 = lmc[min(g + 4 * u, m - 1)];
+        const int ju = min(g + 4 * u, m - 1);
+        const int c0 = lmc[ju];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) plr[u][d] = P[(int64_t)(c0 + d) * ld + c];
+        for (int d = 0; d < 3; ++d)
+            plr[u][d] = prow ? prow[(int64_t)(EKF_CAM + 3 * ju + d) * fr.ldw + c] : P[(int64_t)(c0 + d) * ld + c];
     }
     if (tid < m) {
         const int c0 = lmc[tid];
@@ -264,91 +269,136 @@ __device__ __forceinline__ void ekf_solve_emit_lop(const EkfFrame& fr, const dou
     }
 }
 
+// Left-looking update of one 16x16 block:  S[rows of block i][cb .. cb+15] -= sum_{q in [q0,q1)} L_iq L_bq^T
+// (b = cb / 16).  One wave; two independent MFMA chains.  Row block nb is the residual row (all 16
+// operand rows alias row kp, only row 0 is stored).
+__device__ __forceinline__ void ekf_solve_update_block(double* S, int LD, int kp, int i, int cb,
+                                                       int q0, int q1, int c, int g) {
+    const int rbase = EKF_RB * i;
+    const double* arow = S + (size_t)min(rbase + c, kp) * LD + g;
+    const double* brow = S + (size_t)(cb + c) * LD + g;
+    sf64x4 t, t2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[r] = S[min(rbase + g + 4 * r, kp) * LD + cb + c];
+    int q = q0;
+    for (; q + 1 < q1; q += 2) {
+        double av[8], bv[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            av[r] = arow[EKF_RB * q + 4 * r];     // A[i = c][k = g + 4r]
+            bv[r] = brow[EKF_RB * q + 4 * r];     // B[k][j = c] = L[cb + c][k]
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            t = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[r], bv[r], t, 0, 0, 0);
+            t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[4 + r], bv[4 + r], t2, 0, 0, 0);
+        }
+    }
+    if (q < q1) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { av[r] = arow[EKF_RB * q + 4 * r]; bv[r] = brow[EKF_RB * q + 4 * r]; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[r], bv[r], t, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = rbase + g + 4 * r;
+        if (row <= kp) S[row * LD + cb + c] = t[r] + t2[r];
+    }
+}
+
 // MS = 5: m <= 32 detections, MS = 6: m <= 64.  Pair p -> (row r1 = p >> MS, detection
-// jp = p & (2^MS - 1)); a thread's pairs all share jp (256 is a multiple of 2^MS).
+// jp = p & (2^MS - 1)); a thread's pairs all share jp (the block size is a multiple of 2^MS).
+#define EKF_SOLVE_THREADS 512
 template <int MS>
-__global__ __launch_bounds__(256) void ekf_solve_blocked_kernel(EkfFrame fr) {
+__global__ __launch_bounds__(EKF_SOLVE_THREADS) void ekf_solve_blocked_kernel(EkfFrame fr) {
     extern __shared__ __attribute__((aligned(16))) double b_sm[];
+    constexpr int NT = EKF_SOLVE_THREADS;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c = lane & 15, g = lane >> 4;
     const int k = fr.k, kp = fr.kpad, nb = kp / EKF_RB, LD = kp + 2, m = fr.m;
     double* S = b_sm;                                   // [kp + 1][LD], row kp = residual
     double* invd = S + (size_t)(kp + 1) * LD;           // [kp]  1 / L_jj
     double* ac = invd + kp + 2;                         // [k][10]  A[:, 0:10]
+    double* hl = ac + (size_t)k * EKF_CAM;              // [k][13]
     int nstamp = 0;
 #define EKF_STAMP() do { if (fr.stamps && tid == 0) fr.stamps[nstamp] = clock64(); ++nstamp; } while (0)
     EKF_STAMP();
     // ---- build S = A[:, support] H^T + R (lower triangle).
     // asup (row stride LD) is copied flat into S with coalesced 16-byte loads; entry
     // S[r1][3jp+d] is then computed in place from S[r1][3jp..3jp+2] = asup[r1][3jp..3jp+2].
-    constexpr int RSTEP = 256 >> MS;                    // rows advanced per pair slot
-    constexpr int NPAIR = 16;                           // pair slots per batch
+    constexpr int RSTEP = NT >> MS;                     // rows advanced per pair slot
+    constexpr int NPAIR = 128 / RSTEP;                  // pair slots: 128 rows per batch
     const int jp = tid & ((1 << MS) - 1);
     const bool jvalid = jp < m;
-    double* hl = ac + (size_t)k * EKF_CAM;              // [k][13]
     {
         const int n16 = (k * LD) >> 1;                  // k * LD is even (LD even)
         const double2* src = reinterpret_cast<const double2*>(fr.asup);
         double2* dst = reinterpret_cast<double2*>(S);
-        double2 v[20];
+        constexpr int NV = 10;                          // 10 * 512 double2 = 10240 doubles >= 96 * 98
+        double2 v[NV];
 #pragma unroll
-        for (int i = 0; i < 20; ++i) {
-            const int e = tid + 256 * i;
-            v[i] = (e < n16) ? src[e] : make_double2(0.0, 0.0);
+        for (int i = 0; i < NV; ++i) {
+            const int e = tid + NT * i;
+            v[i] = src[min(e, n16 - 1)];
         }
-        double acv[8], hv[8];
+        double acv[4], hv[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int e = tid + 256 * i, r = e >> 4, cc = e & 15;
-            acv[i] = (r < k && cc < EKF_CAM) ? fr.amat[(int64_t)r * fr.lda + cc] : 0.0;
-            hv[i] = (r < k) ? fr.jac[e] : 0.0;          // jac is [k][16], contiguous
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + NT * i, r = min(e >> 4, k - 1), cc = e & 15;
+            acv[i] = fr.amat[(int64_t)r * fr.lda + min(cc, EKF_CAM - 1)];
+            hv[i] = fr.jac[min(e, k * EKF_JLD - 1)];    // jac is [k][16], contiguous
         }
-        const double rres = (tid < k) ? fr.resid[tid] : 0.0;
+        const double rres = fr.resid[min(tid, k - 1)];
 #pragma unroll
-        for (int i = 0; i < 20; ++i) {
-            const int e = tid + 256 * i;
+        for (int i = 0; i < NV; ++i) {
+            const int e = tid + NT * i;
             if (e < n16) dst[e] = v[i];
         }
-        for (int e = tid + 256 * 20; e < n16; e += 256) dst[e] = src[e];   // (k * LD > 10240 doubles)
+        for (int e = tid + NT * NV; e < n16; e += NT) dst[e] = src[e];   // (k * LD > 10240 doubles)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int e = tid + 256 * i, r = e >> 4, cc = e & 15;
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + NT * i, r = e >> 4, cc = e & 15;
             if (r < k && cc < EKF_CAM) ac[r * EKF_CAM + cc] = acv[i];
             if (r < k && cc < EKF_JCOLS) hl[r * EKF_JCOLS + cc] = hv[i];
         }
         // padding rows k..kp-1 = identity, residual row kp
         const int tr = tid >> 4, tc = tid & 15;
-        for (int r = k + tr; r <= kp; r += 16) {
+        for (int r = k + tr; r <= kp; r += NT / 16) {
             const int hi = (r < kp) ? (r | 15) : kp - 1;
             for (int cc = tc; cc <= hi; cc += 16) S[r * LD + cc] = (r < kp && cc == r) ? 1.0 : 0.0;
         }
         __syncthreads();
+        EKF_STAMP();
         if (tid < k) S[kp * LD + tid] = rres;
     }
-    double hreg[3][EKF_JCOLS];                          // this thread's 3 Jacobian rows
+    {
+        double hreg[3][EKF_JCOLS];                      // this thread's 3 Jacobian rows
 #pragma unroll
-    for (int d = 0; d < 3; ++d)
+        for (int d = 0; d < 3; ++d)
 #pragma unroll
-        for (int a = 0; a < EKF_JCOLS; ++a)
-            hreg[d][a] = jvalid ? hl[(3 * jp + d) * EKF_JCOLS + a] : 0.0;
-    for (int r0 = 0; r0 < k; r0 += NPAIR * RSTEP) {     // one batch for m <= 32, k <= 128
+            for (int a = 0; a < EKF_JCOLS; ++a)
+                hreg[d][a] = hl[(3 * min(jp, m - 1) + d) * EKF_JCOLS + a];
+        for (int r0 = 0; r0 < k; r0 += 128) {           // one batch for k <= 128
 #pragma unroll
-        for (int u = 0; u < NPAIR; ++u) {
-            const int r1 = r0 + (tid >> MS) + RSTEP * u;
-            if (jvalid && r1 < k && r1 >= 3 * jp) {
-                double* sp = S + r1 * LD + 3 * jp;
-                const double a0 = sp[0], a1 = sp[1], a2 = sp[2];
-                double a10[EKF_CAM];
+            for (int u = 0; u < NPAIR; ++u) {
+                const int r1 = r0 + (tid >> MS) + RSTEP * u;
+                if (jvalid && r1 < k && r1 >= 3 * jp) {
+                    double* sp = S + r1 * LD + 3 * jp;
+                    const double a0 = sp[0], a1 = sp[1], a2 = sp[2];
+                    double a10[EKF_CAM];
 #pragma unroll
-                for (int bb = 0; bb < EKF_CAM; ++bb) a10[bb] = ac[r1 * EKF_CAM + bb];
+                    for (int bb = 0; bb < EKF_CAM; ++bb) a10[bb] = ac[r1 * EKF_CAM + bb];
 #pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    const int r2 = 3 * jp + d;
-                    double acc = (r1 == r2) ? fr.nz.r_unc : 0.0;
+                    for (int d = 0; d < 3; ++d) {
+                        const int r2 = 3 * jp + d;
+                        double acc = (r1 == r2) ? fr.nz.r_unc : 0.0;
 #pragma unroll
-                    for (int bb = 0; bb < EKF_CAM; ++bb) acc += a10[bb] * hreg[d][bb];
-                    acc += a0 * hreg[d][10] + a1 * hreg[d][11] + a2 * hreg[d][12];
-                    sp[d] = (r2 <= r1) ? acc : 0.0;   // strict upper part of a diagonal block = 0
+                        for (int bb = 0; bb < EKF_CAM; ++bb) acc += a10[bb] * hreg[d][bb];
+                        acc += a0 * hreg[d][10] + a1 * hreg[d][11] + a2 * hreg[d][12];
+                        sp[d] = (r2 <= r1) ? acc : 0.0;   // strict upper part of a diagonal block = 0
+                    }
                 }
             }
         }
@@ -356,59 +406,26 @@ __global__ __launch_bounds__(256) void ekf_solve_blocked_kernel(EkfFrame fr) {
     __syncthreads();
     EKF_STAMP();
 
+    // ---- blocked left-looking Cholesky.  8 waves:
+    //  (A) all waves : block column b -= L[:, b-1] L[b, b-1]^T  (the older terms were already applied)
+    //  (B) waves 0-2 : the 16-pivot chain of block b (lane = row, v_readlane broadcast)
+    //      waves 3-6 : meanwhile apply the finished block columns 0..b-1 to block column b+1
+    //      wave  7   : meanwhile emit the panel kernel's operands of block column b-1
     int bad = 0;
     for (int b = 0; b < nb; ++b) {
         const int cb = EKF_RB * b;
         if (b > 0) {
-            // ---- phase 1: row blocks b .. nb (nb = residual row), round-robin over waves
-            for (int i = b + wave; i <= nb; i += 4) {
-                const int rbase = EKF_RB * i;
-                const double* arow = S + (size_t)min(rbase + c, kp) * LD + g;   // residual block aliases row kp
-                const double* brow = S + (size_t)(cb + c) * LD + g;
-                sf64x4 t;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) t[r] = S[min(rbase + g + 4 * r, kp) * LD + cb + c];
-                sf64x4 t2 = {0.0, 0.0, 0.0, 0.0};           // second chain: halves the dependent MFMA depth
-                int q = 0;
-                for (; q + 1 < b; q += 2) {
-                    double av[8], bv[8];
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        av[r] = arow[EKF_RB * q + 4 * r];     // A[i = c][k = g + 4r]
-                        bv[r] = brow[EKF_RB * q + 4 * r];     // B[k][j = c] = L[cb + c][k]
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        t = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[r], bv[r], t, 0, 0, 0);
-                        t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[4 + r], bv[4 + r], t2, 0, 0, 0);
-                    }
-                }
-                if (q < b) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        t = __builtin_amdgcn_mfma_f64_16x16x4f64(-arow[EKF_RB * q + 4 * r],
-                                                                 brow[EKF_RB * q + 4 * r], t, 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) t[r] += t2[r];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = rbase + g + 4 * r;
-                    if (row <= kp) S[row * LD + cb + c] = t[r];
-                }
-            }
+            for (int i = b + wave; i <= nb; i += 8) ekf_solve_update_block(S, LD, kp, i, cb, b - 1, b, c, g);
             __syncthreads();
         }
         EKF_STAMP();
-        // ---- phase 2: 16 pivots, lane = row, pivot row broadcast by v_readlane.
-        //  wave 0          : rows cb .. cb+63
-        //  wave 1          : lanes 0-15 the diagonal rows again (every wave needs the pivot rows in
-        //                    its own lanes), lanes 16-31 the rows of I_16 -- the same recurrence
-        //                    turns e_i into row i of L_bb^-T, i.e. column i of Dinv_b for free --,
-        //                    lanes 32-63 rows cb+64 .. cb+95
-        //  waves 2, 3      : lanes 0-15 diagonal rows, lanes 16-63 rows cb+96+48(w-2) ..
-        const int xrow0 = (wave == 1) ? cb + 64 : cb + 96 + 48 * (wave - 2);
-        if (wave <= 1 || xrow0 <= kp) {
+        //  wave 0 : rows cb .. cb+63
+        //  wave 1 : lanes 0-15 the diagonal rows again (every wave needs the pivot rows in its own
+        //           lanes), lanes 16-31 the rows of I_16 -- the same recurrence turns e_i into row i
+        //           of L_bb^-T, i.e. column i of Dinv_b, for free --, lanes 32-63 rows cb+64 .. cb+95
+        //  wave 2 : lanes 0-15 diagonal rows, lanes 16-63 rows cb+96 .. cb+143 (kp <= 128: enough)
+        const int xrow0 = (wave == 1) ? cb + 64 : cb + 96;
+        if (wave <= 1 || (wave == 2 && xrow0 <= kp)) {
             int row;
             if (wave == 0 || lane < EKF_RB) row = cb + lane;
             else if (wave == 1) row = (lane < 32) ? -1 : xrow0 + (lane - 32);
@@ -450,17 +467,21 @@ __global__ __launch_bounds__(256) void ekf_solve_blocked_kernel(EkfFrame fr) {
 #pragma unroll
                 for (int j = 0; j < EKF_RB; ++j) invd[cb + j] = ys[j];
             }
-        } else if (wave == 3 && b > 0) {
-            ekf_solve_emit_lop(fr, S, LD, nb, b - 1, lane);   // idle wave: operands of block column b-1
+        } else if (wave >= 3 && wave <= 6) {
+            if (b > 0 && b + 1 < nb)                     // rows of blocks b+1 .. nb (nb = residual row)
+                for (int i = b + 1 + (wave - 3); i <= nb; i += 4)
+                    ekf_solve_update_block(S, LD, kp, i, cb + EKF_RB, 0, b, c, g);
+        } else if (wave == 7 && b > 0) {
+            ekf_solve_emit_lop(fr, S, LD, nb, b - 1, lane);
         }
         __syncthreads();
         EKF_STAMP();
     }
     if (bad && lane == 0) atomicOr(fr.status, 1);
     // (block column nb-1 has no -L blocks below it)
-    for (int j = tid; j < kp; j += 256) fr.yvec[j] = S[kp * LD + j];
+    for (int j = tid; j < kp; j += NT) fr.yvec[j] = S[kp * LD + j];
     if (fr.wdbg) {                                      // dense L for tests only
-        for (int i = tid >> 4; i < kp; i += 16)
+        for (int i = tid >> 4; i < kp; i += NT / 16)
             for (int j = tid & 15; j < kp; j += 16)
                 fr.lmat[(size_t)i * fr.ldl + j] = (j <= i) ? S[i * LD + j] : 0.0;
     }
@@ -481,9 +502,9 @@ void ekf_launch_solve(const EkfFrame& fr, hipStream_t s) {
     }
     const int lds = ekf_solve_blocked_lds_bytes(fr.kpad, fr.k);
     if (fr.kpad <= 128 && fr.m <= 32)
-        hipLaunchKernelGGL(ekf_solve_blocked_kernel<5>, dim3(1), dim3(256), lds, s, fr);
+        hipLaunchKernelGGL(ekf_solve_blocked_kernel<5>, dim3(1), dim3(EKF_SOLVE_THREADS), lds, s, fr);
     else if (fr.kpad <= 128)
-        hipLaunchKernelGGL(ekf_solve_blocked_kernel<6>, dim3(1), dim3(256), lds, s, fr);
+        hipLaunchKernelGGL(ekf_solve_blocked_kernel<6>, dim3(1), dim3(EKF_SOLVE_THREADS), lds, s, fr);
     else
         hipLaunchKernelGGL(ekf_solve_kernel, dim3(1), dim3(256), ekf_solve_lds_bytes(fr.kpad), s, fr);
 }

@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = (
 class EkfConfig(C.Structure):
     _fields_ = [
         ("max_landmarks", C.c_int32), ("max_visible", C.c_int32), ("cov_dtype", C.c_int32),
-        ("quat_mode", C.c_int32), ("cov_kernel", C.c_int32), ("reserved", C.c_int32),
+        ("quat_mode", C.c_int32), ("cov_kernel", C.c_int32), ("flags", C.c_int32),
         ("initial_camera_uncertainty", C.c_double), ("initial_landmark_uncertainty", C.c_double),
         ("r_uncertainty", C.c_double), ("q_cam", C.c_double), ("q_err", C.c_double),
         ("q_lm", C.c_double), ("stream", C.c_void_p),
@@ -109,7 +109,8 @@ class HipEkf:
     KERNEL_NAMES = ("gather", "solve", "panel", "cov_update")
 
     def __init__(self, max_landmarks: int, max_visible: int, cov_dtype="float64",
-                 quat_mode="as_written", cov_kernel="auto", device="cuda:0", noise=None):
+                 quat_mode="as_written", cov_kernel="auto", device="cuda:0", noise=None,
+                 lookahead=None):
         import torch
         self._torch = torch
         self.lib = load_library()
@@ -125,6 +126,7 @@ class HipEkf:
                          "scalar_first": EKF_QUAT_SCALAR_FIRST}[quat_mode]
         kern = {"auto": EKF_COVK_AUTO, "valu": EKF_COVK_VALU, "mfma": EKF_COVK_MFMA}
         cfg.cov_kernel = kern[cov_kernel]
+        cfg.flags = {None: 0, False: 1, True: 2}[lookahead]   # None = automatic
         for key, val in (noise or {}).items():
             setattr(cfg, key, float(val))
         self.cov_dtype = str(cov_dtype)

@@ -58,7 +58,9 @@ typedef struct ekf_config {
     int32_t cov_dtype;      /* EKF_COV_F64 / EKF_COV_F32 */
     int32_t quat_mode;      /* EKF_QUAT_* */
     int32_t cov_kernel;     /* EKF_COVK_*: covariance-update kernel */
-    int32_t reserved;
+    int32_t flags;          /* cross-frame lookahead of ekf_observe_sequence_device: 0 = automatic
+                             * (on when 3n+10 >= 6144, where the big update dominates), bit 0 = never,
+                             * bit 1 = always */
     /* noise constants, defaults = extended_kalman_filter.py:21-27 */
     double initial_camera_uncertainty;   /* 0.1  */
     double initial_landmark_uncertainty; /* 0.7  */
@@ -109,7 +111,12 @@ int ekf_observe_device(ekf_filter *f, const int32_t *lm_index_dev,
 
 /* `frames` consecutive observe() calls on device-resident detections
  * lm_index_dev [frames,m], z_dev [frames,m,3]; after every frame the camera
- * pose state[0:7] is appended to trajectory_dev [frames,7] (may be NULL). */
+ * pose state[0:7] is appended to trajectory_dev [frames,7] (may be NULL).
+ * Because the next frame's detections are known, the rows of the updated
+ * covariance that frame t+1 reads are produced first by a small kernel, and the
+ * big covariance update of frame t runs on an internal second stream while
+ * frame t+1's gather/solve/panel proceed (same arithmetic per element: results
+ * are bitwise those of per-frame ekf_observe calls). */
 int ekf_observe_sequence_device(ekf_filter *f, const int32_t *lm_index_dev,
                                 const double *z_dev, int32_t m, int32_t frames,
                                 double *trajectory_dev);

@@ -253,33 +253,42 @@ def test_full_size_properties_n1024_fp32():
     assert float(cov_t[dims:, :].abs().max()) == 0.0 and float(cov_t[:, dims:].abs().max()) == 0.0
 
 
-def test_resident_sequence_entry_matches_per_frame_calls():
+@pytest.mark.parametrize("dtype,kernel", [("float64", "mfma"), ("float32", "mfma"), ("float32", "valu")])
+def test_resident_sequence_entry_matches_per_frame_calls(dtype, kernel):
+    """ekf_observe_sequence_device (cross-frame lookahead: priority rows + big update on a
+    second stream) must give BITWISE the results of per-frame observe() calls, also with a
+    landmark detected twice in a frame and with the lookahead switched off."""
     import torch
     from aruco_slam_amd.synthetic import SyntheticStream
     outs = []
-    for batched in (False, True):
+    for mode in ("per_frame", "sequence", "sequence_no_lookahead"):
         s = SyntheticStream(64, 8, seed=2)
-        flt = _ekf(max_landmarks=64, max_visible=8)
+        flt = _ekf(max_landmarks=64, max_visible=8, cov_dtype=dtype, cov_kernel=kernel,
+                   lookahead=(mode != "sequence_no_lookahead"))   # True forces it on at this size
         for ids, poses in s.bootstrap():
             flt.observe(ids, poses)
-        frames = list(s.steady(6))
-        if batched:
-            idx = torch.tensor(np.stack([f[0] for f in frames]), dtype=torch.int32, device="cuda")
-            z = torch.tensor(np.stack([f[1][:, :3] for f in frames]), dtype=torch.float64,
-                             device="cuda")
-            traj = torch.zeros((len(frames), 7), dtype=torch.float64, device="cuda")
-            flt.backend.observe_sequence(idx, z, traj)
-            flt.backend.sync()
-            tr = traj.cpu().numpy()
-        else:
+        frames = [(ids.copy(), poses.copy()) for ids, poses in s.steady(9)]
+        frames[3][0][5] = frames[3][0][1]            # duplicate detection in frame 3
+        frames[4][0][:] = frames[4][0][0]            # one landmark seen 8 times (> 4 slot list)
+        if mode == "per_frame":
             tr = []
             for ids, poses in frames:
                 flt.observe(ids, poses)
                 tr.append(flt.state[:7].copy())
             tr = np.stack(tr)
+        else:
+            idx = torch.tensor(np.stack([f[0] for f in frames]), dtype=torch.int32, device="cuda")
+            z = torch.tensor(np.stack([f[1][:, :3] for f in frames]), dtype=torch.float64,
+                             device="cuda")
+            traj = torch.zeros((len(frames), 7), dtype=torch.float64, device="cuda")
+            flt.backend.observe_sequence(idx[:5], z[:5], traj[:5])     # two calls back to back:
+            flt.backend.observe_sequence(idx[5:], z[5:], traj[5:])     # the join must hold
+            flt.backend.sync()
+            tr = traj.cpu().numpy()
         outs.append((tr, flt.state, flt.uncertainty))
-    for a, b in zip(outs[0], outs[1]):
-        assert np.array_equal(a, b)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert np.array_equal(a, b)
 
 
 def test_error_behaviour():
