@@ -144,13 +144,12 @@ __global__ __launch_bounds__(256) void ekf_cov_update_mfma_f32(EkfFrame fr, int 
             if (k0 + u < 8 * KB) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-a[u], b[u], acc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
+    const float qlane = (I == J) ? (float)ekf_qdiag(i0 + l31, fr.dims, fr.nz) : 0.0f;
     float out[16];
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         const int rl = (reg & 3) + 8 * (reg >> 2) + 4 * lhi;
-        float v = pt[reg];
-        if (I == J && rl == l31) v += (float)ekf_qdiag(i0 + rl, fr.dims, fr.nz);
-        v += acc[reg];
+        const float v = (pt[reg] + ((rl == l31) ? qlane : 0.0f)) + acc[reg];
         out[reg] = v;
         P[(int64_t)(i0 + rl) * ld + j0 + l31] = v;
     }
