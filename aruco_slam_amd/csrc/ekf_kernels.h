@@ -24,6 +24,8 @@ struct EkfFrame {
     double* asup;          // A restricted to the landmark support columns: asup[r][3 jp + e] =
                            // A[r][lmcol[jp] + e], [kmax, ldas]  (what S = A H^T needs besides A[:,0:10])
     int32_t ldas;
+    double* asupt;         // the same, slot-major: asupt[3 jp + e][r], [kmax, ldast] (coalesced for the solve)
+    int32_t ldast;
     double* lmat;          // Cholesky factor L of S, [kmax, ldl] f64 (lower)
     int32_t ldl;
     double* dinv;          // inverse of the 16x16 diagonal blocks of L, [kmax/16,16,16]

@@ -9,6 +9,8 @@
 //
 // The reference forms K = P H^T S^-1 and P <- (I - K H) P.  With S = L L^T and
 // W = L^-1 H P (P symmetric) this is dx = W^T L^-1 (z-h) and P <- P - W^T W.
+#include <cstdlib>
+
 #include "ekf_kernels.h"
 
 // --------------------------------------------------------------------------
@@ -107,11 +109,17 @@ __global__ __launch_bounds__(256) void ekf_gather_kernel(EkfFrame fr) {
                     if (nslot <= 4) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            if (q < nslot) fr.asup[(size_t)r * fr.ldas + slots[q]] = acc;
+                            if (q < nslot) {
+                                fr.asup[(size_t)r * fr.ldas + slots[q]] = acc;
+                                fr.asupt[(size_t)slots[q] * fr.ldast + r] = acc;
+                            }
                     } else {                       // > 4 detections of one landmark in a frame
                         for (int jp = 0; jp < m; ++jp)
                             for (int e = 0; e < 3; ++e)
-                                if (lmc[jp] + e == c) fr.asup[(size_t)r * fr.ldas + 3 * jp + e] = acc;
+                                if (lmc[jp] + e == c) {
+                                    fr.asup[(size_t)r * fr.ldas + 3 * jp + e] = acc;
+                                    fr.asupt[(size_t)(3 * jp + e) * fr.ldast + r] = acc;
+                                }
                     }
                 }
             }
@@ -489,6 +497,318 @@ __global__ __launch_bounds__(EKF_SOLVE_THREADS) void ekf_solve_blocked_kernel(Ek
 #undef EKF_STAMP
 }
 
+// --------------------------------------------------------------------------
+// solve, column-streaming blocked Cholesky (kpad <= 192).  16 waves, one workgroup.
+//   * only 4 block columns of S live in LDS (ring); a finished block column b is emitted from
+//     the pivot waves' registers in MFMA-operand order (-L, `lop`) -- the layout the panel kernel
+//     reads anyway -- and is read back from there by the later left-looking updates;
+//   * per block column b:   (A) all waves : column b -= L[:, b-1] L[b, b-1]^T        (LDS operands)
+//                           (B) pivot waves: 16-pivot chain (lane = row, v_readlane broadcast),
+//                               one more wave carries the diagonal rows + I_16 -> Dinv_b;
+//                               every other wave meanwhile: column b+1 -= (q = b-1 term) and
+//                               column b+2 is BUILT (S = A_supp H^T + R from asupt, ac, hl) and gets
+//                               its q <= b-1 terms (lop for q <= b-2, LDS for q = b-1);
+//     so the S build and all but one update term per column hide behind the pivot chain.
+//   * the residual rides along as row kp (its factor row is y = L^-1 (z - h)).
+// --------------------------------------------------------------------------
+#define SV_T 512
+#define SV_CLD 18
+
+__device__ __forceinline__ size_t sv_lop_index(int i, int q) { return (size_t)(i * (i - 1) / 2 + q) * 256; }
+
+// C-in / C-out of row block i of the column buffer `tgt` (block column tc), one wave
+struct SvAcc { sf64x4 t, t2; };
+__device__ __forceinline__ void sv_acc_load(SvAcc& a, const double* tgt, int kp, int i, int c, int g) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        a.t[r] = tgt[min(EKF_RB * i + g + 4 * r, kp) * SV_CLD + c];
+        a.t2[r] = 0.0;
+    }
+}
+__device__ __forceinline__ void sv_acc_store(const SvAcc& a, double* tgt, int kp, int i, int c, int g) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = EKF_RB * i + g + 4 * r;
+        if (row <= kp) tgt[row * SV_CLD + c] = a.t[r] + a.t2[r];
+    }
+}
+// one q term, operands from the LDS buffer of block column q:  -= L_iq L_tq^T
+__device__ __forceinline__ void sv_term_lds(SvAcc& a, const double* qbuf, int kp, int i, int tc, int c, int g,
+                                            bool second = false) {
+    const double* ar = qbuf + (size_t)min(EKF_RB * i + c, kp) * SV_CLD + g;   // residual block: rows alias kp
+    const double* br = qbuf + (size_t)(EKF_RB * tc + c) * SV_CLD + g;
+    double av[4], bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { av[r] = ar[4 * r]; bv[r] = br[4 * r]; }
+    if (second) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a.t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[r], bv[r], a.t2, 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a.t = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[r], bv[r], a.t, 0, 0, 0);
+    }
+}
+// q in [0, q1), operands from global: lop (-L blocks) and, for the residual block, y
+__device__ __forceinline__ void sv_terms_glb(SvAcc& a, const double* __restrict__ lop,
+                                             const double* __restrict__ yv, int nb, int i, int tc, int q1,
+                                             int g, int lane) {
+    if (q1 <= 0) return;
+    // operands of term q+1 are in flight while the MFMAs of term q run
+    double av[4], bv[4], an[4], bn[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        av[r] = (i < nb) ? lop[sv_lop_index(i, 0) + r * 64 + lane] : -yv[g + 4 * r];
+        bv[r] = -lop[sv_lop_index(tc, 0) + r * 64 + lane];
+    }
+    for (int q = 0; q < q1; ++q) {
+        const int qn = min(q + 1, q1 - 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            an[r] = (i < nb) ? lop[sv_lop_index(i, qn) + r * 64 + lane] : -yv[EKF_RB * qn + g + 4 * r];
+            bn[r] = -lop[sv_lop_index(tc, qn) + r * 64 + lane];
+        }
+        if (q & 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a.t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[r], bv[r], a.t2, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a.t = __builtin_amdgcn_mfma_f64_16x16x4f64(av[r], bv[r], a.t, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { av[r] = an[r]; bv[r] = bn[r]; }
+    }
+}
+
+// S entries of row block i of block column tc (rows 16i.., columns 16tc..): one wave, lane =
+// (row rr = lane & 15, column group cg = lane >> 4 -> 4 columns)
+struct SvBuild { double as[4][3]; double rs[4]; };
+// global loads of one block (branch-free, clamped) ...
+__device__ __forceinline__ void sv_build_load(const EkfFrame& fr, SvBuild& w, int kp, int nb, int i, int tc,
+                                              int lane) {
+    const int k = fr.k, rr = lane & 15, cg = lane >> 4;
+    const int r1c = min((i == nb) ? kp : EKF_RB * i + rr, k - 1);
+    const int r2b = EKF_RB * tc + 4 * cg;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        const int r2c = min(r2b + x, k - 1);
+        const int jp = (r2c * 43691) >> 17;            // r2 / 3 for r2 < 98304
+        const double* ap = fr.asupt + (size_t)(3 * jp) * fr.ldast + r1c;
+        w.as[x][0] = ap[0];
+        w.as[x][1] = ap[fr.ldast];
+        w.as[x][2] = ap[2 * fr.ldast];
+        w.rs[x] = fr.resid[r2c];
+    }
+}
+// ... and the arithmetic: S entries of row block i of block column tc (rows 16i.., columns 16tc..);
+// one wave, lane = (row rr = lane & 15, column group cg = lane >> 4 -> 4 columns)
+__device__ __forceinline__ void sv_build_finish(const EkfFrame& fr, const SvBuild& w, double* tgt,
+                                                const double* ac, const double* hl, int kp, int nb, int i,
+                                                int tc, int lane) {
+    const int k = fr.k, rr = lane & 15, cg = lane >> 4;
+    const bool is_res = (i == nb);
+    if (is_res && rr != 0) return;                     // residual row block: one row
+    const int r1 = is_res ? kp : EKF_RB * i + rr;
+    const int r1c = min(r1, k - 1);
+    const int r2b = EKF_RB * tc + 4 * cg;
+    double a10[EKF_CAM];
+#pragma unroll
+    for (int bb = 0; bb < EKF_CAM; ++bb) a10[bb] = ac[r1c * EKF_CAM + bb];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        const int r2 = r2b + x;
+        const double* h2 = hl + min(r2, k - 1) * EKF_JCOLS;
+        double acc = (r1 == r2) ? fr.nz.r_unc : 0.0;
+#pragma unroll
+        for (int bb = 0; bb < EKF_CAM; ++bb) acc += a10[bb] * h2[bb];
+        acc += w.as[x][0] * h2[10] + w.as[x][1] * h2[11] + w.as[x][2] * h2[12];
+        const bool pad = (r1 >= k) || (r2 >= k);       // identity padding rows / columns
+        double v = (r2 > r1) ? 0.0 : acc;              // strict upper part of a diagonal block
+        v = pad ? ((r1 == r2) ? 1.0 : 0.0) : v;
+        v = is_res ? ((r2 < k) ? w.rs[x] : 0.0) : v;
+        tgt[r1 * SV_CLD + 4 * cg + x] = v;
+    }
+}
+__device__ __forceinline__ void sv_build_block(const EkfFrame& fr, double* tgt, const double* ac,
+                                               const double* hl, int kp, int nb, int i, int tc, int lane) {
+    SvBuild w;
+    sv_build_load(fr, w, kp, nb, i, tc, lane);
+    sv_build_finish(fr, w, tgt, ac, hl, kp, nb, i, tc, lane);
+}
+
+// number of block columns resident in LDS: all of them when they fit (kpad <= 112), else a ring
+int ekf_solve_stream_ring(int kpad, int k) {
+    const size_t col = (size_t)(kpad + 1) * SV_CLD * sizeof(double);
+    const size_t fixed = ((size_t)k * (EKF_CAM + EKF_JCOLS) + 8) * sizeof(double);
+    int rs = (int)((160 * 1024 - fixed) / col);
+    const int nb = kpad / EKF_RB;
+    if (rs > nb) rs = nb;
+    return rs < 4 ? 4 : rs;
+}
+int ekf_solve_stream_lds_bytes(int kpad, int k) {
+    return (int)(((size_t)ekf_solve_stream_ring(kpad, k) * (kpad + 1) * SV_CLD +
+                  (size_t)k * (EKF_CAM + EKF_JCOLS) + 8) * sizeof(double));
+}
+
+__global__ __launch_bounds__(SV_T) void ekf_solve_stream_kernel(EkfFrame fr, int RS) {
+    extern __shared__ __attribute__((aligned(16))) double v_sm[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+    const int k = fr.k, kp = fr.kpad, nb = kp / EKF_RB, rows = kp + 1;
+    // RS block columns live in LDS: all of them (RS == nb) or a ring (column c in slot c % RS,
+    // overwritten when column c + RS is built, i.e. during iteration c + RS - 2)
+    double* ring = v_sm;                                         // [RS][rows][SV_CLD]
+    double* ac = ring + (size_t)RS * rows * SV_CLD;              // [k][10]
+    const bool all_resident = RS >= nb;
+    double* hl = ac + (size_t)k * EKF_CAM;                       // [k][13]
+    auto colbuf = [&](int col) { return ring + (size_t)(col % RS) * rows * SV_CLD; };
+    constexpr int NW = SV_T / 64;
+    int nstamp = 0;
+#define EKF_STAMP() do { if (fr.stamps && tid == 0) fr.stamps[nstamp] = clock64(); ++nstamp; } while (0)
+    EKF_STAMP();
+    // prologue.  Block columns built before the first pivot chain: all of them when they are all
+    // resident, else 0 and 1 (column c >= 2 is then built during iteration c - 2).  The global
+    // loads of this wave's first PB blocks are issued together with the ac / hl staging loads:
+    // one exposed memory round trip instead of one per block.
+    constexpr int PB = 5;
+    const int ncol0 = all_resident ? nb : (nb > 1 ? 2 : 1);
+    int ntot = 0;
+    for (int tc = 0; tc < ncol0; ++tc) ntot += nb - tc + 1;
+    SvBuild pw[PB];
+    int pi[PB], ptc[PB];
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+        int u = wave + NW * j, tc = 0;
+        const bool has = u < ntot;
+        u = has ? u : 0;
+        while (u >= nb - tc + 1) { u -= nb - tc + 1; ++tc; }
+        pi[j] = has ? tc + u : -1;
+        ptc[j] = tc;
+        if (has) sv_build_load(fr, pw[j], kp, nb, pi[j], tc, lane);
+    }
+    EKF_STAMP();
+    for (int e = tid; e < k * 16; e += SV_T) {
+        const int r = e >> 4, cc = e & 15;
+        if (cc < EKF_CAM) ac[r * EKF_CAM + cc] = fr.amat[(int64_t)r * fr.lda + cc];
+        if (cc < EKF_JCOLS) hl[r * EKF_JCOLS + cc] = fr.jac[e];
+    }
+    EKF_STAMP();
+    __syncthreads();
+    EKF_STAMP();
+#pragma unroll
+    for (int j = 0; j < PB; ++j)
+        if (pi[j] >= 0) sv_build_finish(fr, pw[j], colbuf(ptc[j]), ac, hl, kp, nb, pi[j], ptc[j], lane);
+    for (int u0 = wave + NW * PB; u0 < ntot; u0 += NW) {      // (more than PB blocks per wave: rare)
+        int u = u0, tc = 0;
+        while (u >= nb - tc + 1) { u -= nb - tc + 1; ++tc; }
+        sv_build_block(fr, colbuf(tc), ac, hl, kp, nb, tc + u, tc, lane);
+    }
+    __syncthreads();
+    EKF_STAMP();
+
+    int bad = 0;
+    for (int b = 0; b < nb; ++b) {
+        const int cb = EKF_RB * b;
+        double* cur = colbuf(b);
+        if (b > 0) {   // (A) the one term that could not be applied earlier
+            for (int i = b + wave; i <= nb; i += NW) {
+                SvAcc a;
+                sv_acc_load(a, cur, kp, i, c, g);
+                sv_term_lds(a, colbuf(b - 1), kp, i, b, c, g);
+                sv_acc_store(a, cur, kp, i, c, g);
+            }
+            __syncthreads();
+        }
+        EKF_STAMP();
+        // (B) roles.  rows of this block column: cb .. kp (kp = residual row)
+        const int nrows = kp - cb + 1;
+        const int nrw = (nrows > 64) ? (nrows - 64 + 47) / 48 : 0;   // extra row waves after wave 0
+        if (wave <= nrw + 1) {
+            // wave 0: rows cb..cb+63.  waves 1..nrw: lanes 0-15 the diagonal rows again (every wave
+            // needs the pivot rows in its own lanes), lanes 16-63 rows cb+64+48(w-1)...  wave nrw+1:
+            // diagonal rows + the rows of I_16: e_i -> row i of L_bb^-T = column i of Dinv_b.
+            const bool idw = (wave == nrw + 1);
+            int row;
+            if (wave == 0 || lane < EKF_RB) row = cb + lane;
+            else if (idw) row = -1;
+            else row = cb + 64 + 48 * (wave - 1) + (lane - EKF_RB);
+            const bool ident = idw && lane >= EKF_RB && lane < 2 * EKF_RB;
+            const bool live = !idw && (wave == 0 || lane >= EKF_RB) && row <= kp;
+            const double* src = cur + (size_t)min(max(row, 0), kp) * SV_CLD;
+            double a[EKF_RB];
+#pragma unroll
+            for (int x = 0; x < EKF_RB; ++x) a[x] = (row < 0) ? ((x == lane - EKF_RB) ? 1.0 : 0.0) : src[x];
+#pragma unroll
+            for (int j = 0; j < EKF_RB; ++j) {
+                const double d = ekf_readlane_f64(a[j], j);
+                bad |= !(d > 0.0);
+                const double y = ekf_rsqrt_f64(d);
+                const double lj = a[j] * y;
+                a[j] = lj;
+#pragma unroll
+                for (int x = j + 1; x < EKF_RB; ++x) {
+                    const double lx = ekf_readlane_f64(lj, x);
+                    a[x] = __builtin_fma(-lj, lx, a[x]);
+                }
+            }
+            if (live) {
+                double* dst = cur + (size_t)row * SV_CLD;
+#pragma unroll
+                for (int x = 0; x < EKF_RB; ++x) dst[x] = a[x];
+                if (row == kp) {                         // residual row: y of this block
+#pragma unroll
+                    for (int x = 0; x < EKF_RB; ++x) fr.yvec[cb + x] = a[x];
+                } else if (row >= cb + EKF_RB) {         // -L block (row/16, b) in MFMA operand order
+                    const size_t base = sv_lop_index(row >> 4, b) + (row & 15);
+#pragma unroll
+                    for (int x = 0; x < EKF_RB; ++x) fr.lop[base + (x >> 2) * 64 + 16 * (x & 3)] = -a[x];
+                }
+                if (fr.wdbg && row < kp) {               // dense L for tests only
+#pragma unroll
+                    for (int x = 0; x < EKF_RB; ++x) fr.lmat[(size_t)row * fr.ldl + cb + x] = (cb + x <= row) ? a[x] : 0.0;
+                }
+            }
+            if (ident) {                                 // a[x] = Dinv_b[x][i], i = lane - 16
+                const int i = lane - EKF_RB;
+#pragma unroll
+                for (int x = 0; x < EKF_RB; ++x) {
+                    fr.dinv[(size_t)(cb + x) * EKF_RB + i] = a[x];
+                    fr.dop[(size_t)(b * 4 + (i >> 2)) * 64 + x + 16 * (i & 3)] = a[x];
+                }
+            }
+        } else {
+            const int fw = wave - (nrw + 2), nfw = NW - (nrw + 2);   // free waves
+            // block column b+1: the q = b-1 term (operands still in LDS)
+            if (b >= 1 && b + 1 < nb)
+                for (int i = b + 1 + fw; i <= nb; i += nfw) {
+                    SvAcc a;
+                    sv_acc_load(a, colbuf(b + 1), kp, i, c, g);
+                    sv_term_lds(a, colbuf(b - 1), kp, i, b + 1, c, g);
+                    sv_acc_store(a, colbuf(b + 1), kp, i, c, g);
+                }
+            // block column b+2: built here unless it already is; then every finished term q <= b-1
+            // (from LDS while column q is still resident, else from the emitted -L blocks)
+            const int tc = b + 2;
+            if (tc < nb)
+                for (int i = tc + fw; i <= nb; i += nfw) {
+                    if (!all_resident) sv_build_block(fr, colbuf(tc), ac, hl, kp, nb, i, tc, lane);
+                    if (b >= 1) {
+                        SvAcc a;
+                        sv_acc_load(a, colbuf(tc), kp, i, c, g);
+                        int q = 0;
+                        for (; q < b && !(q + RS >= nb || b <= q + RS - 3); ++q) {}   // first resident q
+                        sv_terms_glb(a, fr.lop, fr.yvec, nb, i, tc, q, g, lane);
+                        for (; q < b; ++q) sv_term_lds(a, colbuf(q), kp, i, tc, c, g, (q & 1) != 0);
+                        sv_acc_store(a, colbuf(tc), kp, i, c, g);
+                    }
+                }
+        }
+        __syncthreads();
+        EKF_STAMP();
+    }
+    if (bad && lane == 0) atomicOr(fr.status, 1);
+    EKF_STAMP();
+#undef EKF_STAMP
+}
+
 void ekf_launch_solve(const EkfFrame& fr, hipStream_t s) {
     static bool once = false;
     if (!once) {   // > 64 KB of dynamic LDS needs the opt-in
@@ -499,6 +819,19 @@ void ekf_launch_solve(const EkfFrame& fr, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ekf_solve_blocked_kernel<6>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         once = true;
+    }
+    static const bool old_path = getenv("EKF_SOLVE_OLD") != nullptr;
+    if (!old_path) {
+        static bool once2 = false;
+        if (!once2) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ekf_solve_stream_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            once2 = true;
+        }
+        hipLaunchKernelGGL(ekf_solve_stream_kernel, dim3(1), dim3(SV_T),
+                           ekf_solve_stream_lds_bytes(fr.kpad, fr.k), s, fr,
+                           ekf_solve_stream_ring(fr.kpad, fr.k));
+        return;
     }
     const int lds = ekf_solve_blocked_lds_bytes(fr.kpad, fr.k);
     if (fr.kpad <= 128 && fr.m <= 32)
