@@ -40,7 +40,7 @@ struct Layout {
     int64_t cap;      // padded state dimension (multiple of 128)
     int kmax;         // 3 * max_visible rounded up to 16
     size_t elem;      // sizeof(cov element)
-    size_t off_jac, off_resid, off_y, off_lmcol, off_amat, off_asup, off_asupt, off_lmat, off_dinv, off_lop, off_dop, off_wpanel, off_wpanel2, off_prow, off_wdbg,
+    size_t off_jac, off_resid, off_y, off_lmcol, off_amat, off_sblk, off_lmat, off_dinv, off_lop, off_dop, off_wpanel, off_wpanel2, off_prow, off_wdbg,
         off_idx, off_z, off_status, off_stamps, off_diag, off_xyz, off_unc, total;
 };
 
@@ -56,8 +56,7 @@ Layout make_layout(const ekf_config& c) {
     L.off_y = take((size_t)L.kmax * 8);
     L.off_lmcol = take((size_t)c.max_visible * 4);
     L.off_amat = take((size_t)L.kmax * L.cap * 8);
-    L.off_asup = take((size_t)L.kmax * (L.kmax + 2) * 8);
-    L.off_asupt = take((size_t)L.kmax * L.kmax * 8);
+    L.off_sblk = take((size_t)(L.kmax / EKF_RB) * L.kmax * 16 * 8);
     L.off_lmat = take((size_t)L.kmax * L.kmax * 8);
     L.off_dinv = take((size_t)L.kmax * EKF_RB * 8);
     {
@@ -166,10 +165,8 @@ EkfFrame make_frame(ekf_filter* f, const int32_t* idx_dev, const double* z_dev, 
     fr.lmcol = f->at<int32_t>(L.off_lmcol);
     fr.amat = f->at<double>(L.off_amat);
     fr.lda = L.cap;
-    fr.asup = f->at<double>(L.off_asup);
-    fr.asupt = f->at<double>(L.off_asupt);
-    fr.ldast = L.kmax;
-    fr.ldas = fr.kpad + 2;              // = the solve kernel's LDS row stride
+    fr.sblk = f->at<double>(L.off_sblk);
+    fr.sblk_rows = L.kmax;
     fr.lmat = f->at<double>(L.off_lmat);
     fr.ldl = L.kmax;
     fr.dinv = f->at<double>(L.off_dinv);

@@ -21,11 +21,9 @@ struct EkfFrame {
     int32_t* lmcol;        // [mmax] first state column of each detection
     double* amat;          // A = H (P+Q), [kmax, lda] f64
     int64_t lda;
-    double* asup;          // A restricted to the landmark support columns: asup[r][3 jp + e] =
-                           // A[r][lmcol[jp] + e], [kmax, ldas]  (what S = A H^T needs besides A[:,0:10])
-    int32_t ldas;
-    double* asupt;         // the same, slot-major: asupt[3 jp + e][r], [kmax, ldast] (coalesced for the solve)
-    int32_t ldast;
+    double* sblk;          // S = Hs (P+Q)[supp,supp] Hs^T + R in 16x16 blocks (lower block triangle),
+                           // [block column][sblk_rows][16]: what the solve kernel streams into LDS
+    int32_t sblk_rows;
     double* lmat;          // Cholesky factor L of S, [kmax, ldl] f64 (lower)
     int32_t ldl;
     double* dinv;          // inverse of the 16x16 diagonal blocks of L, [kmax/16,16,16]
@@ -67,4 +65,3 @@ void ekf_launch_add_markers(void* cov, int64_t ld, double* state, int32_t dims,
                             int32_t count, hipStream_t s);
 template <typename T>
 void ekf_launch_cov_diag(const void* cov, int64_t ld, double* out_dev, int32_t count, hipStream_t s);
-int ekf_solve_lds_bytes(int kpad);

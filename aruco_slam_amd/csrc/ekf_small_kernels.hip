@@ -9,8 +9,6 @@
 //
 // The reference forms K = P H^T S^-1 and P <- (I - K H) P.  With S = L L^T and
 // W = L^-1 H P (P symmetric) this is dx = W^T L^-1 (z-h) and P <- P - W^T W.
-#include <cstdlib>
-
 #include "ekf_kernels.h"
 
 // --------------------------------------------------------------------------
@@ -18,35 +16,43 @@
 // --------------------------------------------------------------------------
 // NU = detections per wave slot (m <= 4 NU).  All loads of P are issued branch-free
 // (clamped indices) before anything consumes them.
+//
+// One launch, two kinds of workgroups:
+//   blockIdx.x <  ncols/64 : A = H (P+Q) for a chunk of 64 columns
+//   blockIdx.x >= ncols/64 : one 16x16 block (bi >= bj) of S = Hs (P+Q)[supp,supp] Hs^T + R,
+//                            straight from P, written to `sblk` in the column-block layout the
+//                            solve kernel keeps in LDS.  S does not wait for A, so the single
+//                            workgroup solve kernel starts from a finished S.
+// Both first evaluate h / dh for every detection (one thread each) into LDS.
 template <typename T, int NU>
 __global__ __launch_bounds__(256) void ekf_gather_kernel(EkfFrame fr) {
     extern __shared__ __attribute__((aligned(16))) double g_sm[];
-    __shared__ int scount[64];           // support slots that live in this column chunk
-    __shared__ int sslot[64][4];
     double* hs = g_sm;                                  // [k][13]
-    int* lmc = reinterpret_cast<int*>(g_sm + fr.k * EKF_JCOLS);
+    double* us = g_sm + fr.k * EKF_JCOLS;               // [31][16]  (S blocks only)
+    int* lmc = reinterpret_cast<int*>(us + 31 * 16);
     const int tid = threadIdx.x;
-    const int m = fr.m;
+    const int m = fr.m, k = fr.k;
+    const int nchunk = fr.ncols / 64;
+    const bool sblock = (int)blockIdx.x >= nchunk;
     const int chunk0 = blockIdx.x * 64;
     const int cl = tid & 63;
-    const int c = chunk0 + cl;                     // < ncols <= ld by construction
+    const int c = sblock ? 0 : chunk0 + cl;        // < ncols <= ld by construction
     const int g = tid >> 6;                        // wave index: wave-uniform landmark
     const T* __restrict__ P = static_cast<const T*>(fr.cov);
     const int64_t ld = fr.ld;
-    // camera rows of P for this column and the camera state: independent of idx
     // support rows come from P, or -- cross-frame lookahead -- from the priority-row buffer that
     // ekf_cov_rows_kernel filled with exactly the values the covariance update is writing into P
     const T* __restrict__ prow = static_cast<const T*>(fr.prow);
+    // camera rows of P for this column and the camera state: independent of idx
     T pcr[EKF_CAM];
 #pragma unroll
     for (int a = 0; a < EKF_CAM; ++a) pcr[a] = prow ? prow[(int64_t)a * fr.ldw + c] : P[a * ld + c];
     double cam[EKF_CAM];
 #pragma unroll
     for (int a = 0; a < EKF_CAM; ++a) cam[a] = fr.state[a];
-    if (tid < 64) scount[tid] = 0;
     if (tid < m) lmc[tid] = EKF_CAM + EKF_LM * fr.idx[tid];
     __syncthreads();
-    // landmark rows of P for this wave's detections
+    // landmark rows of P for this wave's detections (A chunks)
     T plr[NU][3];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
@@ -63,13 +69,6 @@ __global__ __launch_bounds__(256) void ekf_gather_kernel(EkfFrame fr) {
         ekf_measure(cam, lm, h, J);
         for (int d = 0; d < 3; ++d)
             for (int a = 0; a < EKF_JCOLS; ++a) hs[(3 * tid + d) * EKF_JCOLS + a] = J[d][a];
-        for (int e = 0; e < 3; ++e) {
-            const int sl = c0 + e - chunk0;
-            if (sl >= 0 && sl < 64) {
-                const int p = atomicAdd(&scount[sl], 1);
-                if (p < 4) sslot[sl][p] = 3 * tid + e;
-            }
-        }
         if (blockIdx.x == 0) {
             for (int d = 0; d < 3; ++d) {
                 for (int a = 0; a < EKF_JCOLS; ++a)
@@ -80,13 +79,63 @@ __global__ __launch_bounds__(256) void ekf_gather_kernel(EkfFrame fr) {
         }
     }
     __syncthreads();
+    if (sblock) {
+        // ---- one block of S: rows 16 bi .., columns 16 bj ..
+        int sb = blockIdx.x - nchunk, bi = 0;
+        while (sb > bi) { sb -= bi + 1; ++bi; }
+        const int bj = sb;
+        const int j0 = (16 * bi) / 3;                  // first detection that touches the block's rows
+        // U[slot][c2] = sum_b Pq[rho(slot)][col(r2, b)] H[r2][b]; rho: slots 0..9 camera rows, slot
+        // 10 + 3 (j - j0) + d row d of detection j (<= 7 detections touch 16 rows)
+        for (int e = tid; e < 31 * 16; e += 256) {
+            const int slot = e >> 4, c2 = e & 15, r2 = 16 * bj + c2;
+            const int j = j0 + (slot - EKF_CAM) / 3, d = (slot - EKF_CAM) % 3;
+            double acc = 0.0;
+            if (r2 < k && (slot < EKF_CAM || j < m)) {
+                const int rho = (slot < EKF_CAM) ? slot : lmc[j] + d;
+                const T* prw = prow ? prow + (int64_t)((slot < EKF_CAM) ? slot : EKF_CAM + 3 * j + d) * fr.ldw
+                                    : P + (int64_t)rho * ld;
+                const double* h2 = hs + r2 * EKF_JCOLS;
+                const int c20 = lmc[r2 / 3];
+                T pv[EKF_JCOLS];
+#pragma unroll
+                for (int b = 0; b < EKF_CAM; ++b) pv[b] = prw[b];
+#pragma unroll
+                for (int b = 0; b < 3; ++b) pv[EKF_CAM + b] = prw[c20 + b];
+#pragma unroll
+                for (int b = 0; b < EKF_JCOLS; ++b) {
+                    const int col = (b < EKF_CAM) ? b : c20 + (b - EKF_CAM);
+                    const double pq = (double)pv[b] + ((col == rho) ? ekf_qdiag(rho, fr.dims, fr.nz) : 0.0);
+                    acc += pq * h2[b];
+                }
+            }
+            us[e] = acc;
+        }
+        __syncthreads();
+        {
+            const int i = tid >> 4, c2 = tid & 15, r1 = 16 * bi + i, r2 = 16 * bj + c2;
+            double v;
+            if (r1 >= k || r2 >= k) {
+                v = (r1 == r2) ? 1.0 : 0.0;            // identity padding
+            } else if (r2 > r1) {
+                v = 0.0;                               // strict upper part of a diagonal block
+            } else {
+                const double* h1 = hs + r1 * EKF_JCOLS;
+                const int s1 = EKF_CAM + 3 * (r1 / 3 - j0);
+                double acc = (r1 == r2) ? fr.nz.r_unc : 0.0;
+#pragma unroll
+                for (int a = 0; a < EKF_CAM; ++a) acc += h1[a] * us[a * 16 + c2];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) acc += h1[EKF_CAM + d] * us[(s1 + d) * 16 + c2];
+                v = acc;
+            }
+            fr.sblk[((size_t)bj * fr.sblk_rows + r1) * 16 + c2] = v;
+        }
+        return;
+    }
     double pc[EKF_CAM];
 #pragma unroll
     for (int a = 0; a < EKF_CAM; ++a) pc[a] = (double)pcr[a] + ((a == c) ? ekf_qdiag(a, fr.dims, fr.nz) : 0.0);
-    const int nslot = scount[cl];
-    int slots[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) slots[q] = sslot[cl][q];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         const int j = g + 4 * u;
@@ -105,23 +154,6 @@ __global__ __launch_bounds__(256) void ekf_gather_kernel(EkfFrame fr) {
 #pragma unroll
                 for (int e = 0; e < 3; ++e) acc += hr[10 + e] * pl[e];
                 fr.amat[(int64_t)r * fr.lda + c] = acc;
-                if (nslot > 0) {
-                    if (nslot <= 4) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            if (q < nslot) {
-                                fr.asup[(size_t)r * fr.ldas + slots[q]] = acc;
-                                fr.asupt[(size_t)slots[q] * fr.ldast + r] = acc;
-                            }
-                    } else {                       // > 4 detections of one landmark in a frame
-                        for (int jp = 0; jp < m; ++jp)
-                            for (int e = 0; e < 3; ++e)
-                                if (lmc[jp] + e == c) {
-                                    fr.asup[(size_t)r * fr.ldas + 3 * jp + e] = acc;
-                                    fr.asupt[(size_t)(3 * jp + e) * fr.ldast + r] = acc;
-                                }
-                    }
-                }
             }
         }
     }
@@ -130,116 +162,19 @@ __global__ __launch_bounds__(256) void ekf_gather_kernel(EkfFrame fr) {
 
 template <typename T>
 void ekf_launch_gather(const EkfFrame& fr, hipStream_t s) {
-    const size_t lds = (size_t)fr.k * EKF_JCOLS * sizeof(double) + (size_t)fr.m * sizeof(int) + 16;
+    const size_t lds = ((size_t)fr.k * EKF_JCOLS + 31 * 16) * sizeof(double) + (size_t)fr.m * sizeof(int) + 16;
+    const int nb = fr.kpad / EKF_RB;
+    const dim3 grid(fr.ncols / 64 + nb * (nb + 1) / 2);
     if (fr.m <= 32)
-        hipLaunchKernelGGL((ekf_gather_kernel<T, 8>), dim3(fr.ncols / 64), dim3(256), lds, s, fr);
+        hipLaunchKernelGGL((ekf_gather_kernel<T, 8>), grid, dim3(256), lds, s, fr);
     else
-        hipLaunchKernelGGL((ekf_gather_kernel<T, 16>), dim3(fr.ncols / 64), dim3(256), lds, s, fr);
+        hipLaunchKernelGGL((ekf_gather_kernel<T, 16>), grid, dim3(256), lds, s, fr);
 }
 template void ekf_launch_gather<float>(const EkfFrame&, hipStream_t);
 template void ekf_launch_gather<double>(const EkfFrame&, hipStream_t);
 
 // --------------------------------------------------------------------------
-// solve: one workgroup.  S (lower, packed) and the augmented residual row live
-// in LDS: (kpad+1)(kpad+2)/2 + kpad doubles  (kpad = 192 -> 151 KB of 160 KB).
-// --------------------------------------------------------------------------
-int ekf_solve_lds_bytes(int kpad) {
-    return (int)(((size_t)(kpad + 1) * (kpad + 2) / 2 + kpad) * sizeof(double));
-}
-
-__global__ __launch_bounds__(256) void ekf_solve_kernel(EkfFrame fr) {
-    extern __shared__ __attribute__((aligned(16))) double s_sm[];
-    const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
-    const int k = fr.k, kp = fr.kpad;
-    double* S = s_sm;
-    double* diag = s_sm + (size_t)(kp + 1) * (kp + 2) / 2;
-#define SP(i, j) S[((i) * ((i) + 1)) / 2 + (j)]
-    // S = A[:, support] H^T + R  (lower triangle); row kp = residual (augmented:
-    // its factor row is y = L^-1 (z - h)); rows k..kp-1 = identity padding.
-    for (int i = ti; i <= kp; i += 16) {
-        for (int j = tj; j <= i && j < kp; j += 16) {
-            double v;
-            if (i == kp) {
-                v = (j < k) ? fr.resid[j] : 0.0;
-            } else if (i >= k) {
-                v = (i == j) ? 1.0 : 0.0;
-            } else {
-                const double* hj = fr.jac + (size_t)j * EKF_JLD;
-                const double* ai = fr.amat + (int64_t)i * fr.lda;
-                const int c0 = fr.lmcol[j / 3];
-                double acc = (i == j) ? fr.nz.r_unc : 0.0;
-#pragma unroll
-                for (int b = 0; b < EKF_CAM; ++b) acc += ai[b] * hj[b];
-#pragma unroll
-                for (int e = 0; e < 3; ++e) acc += ai[c0 + e] * hj[10 + e];
-                v = acc;
-            }
-            SP(i, j) = v;
-        }
-    }
-    __syncthreads();
-    // right-looking Cholesky, column by column
-    for (int j = 0; j < kp; ++j) {
-        const double d = SP(j, j);
-        if (tid == 0) {
-            if (!(d > 0.0)) atomicOr(fr.status, 1);
-            diag[j] = sqrt(d);
-        }
-        const double rs = 1.0 / sqrt(d);
-        for (int i = j + 1 + tid; i <= kp; i += 256) SP(i, j) *= rs;
-        __syncthreads();
-        for (int i = j + 1 + ti; i <= kp; i += 16) {
-            const double li = SP(i, j);
-            const int cmax = (i < kp) ? i : kp - 1;
-            for (int c = j + 1 + tj; c <= cmax; c += 16) SP(i, c) -= li * SP(c, j);
-        }
-        __syncthreads();
-    }
-    for (int i = ti; i < kp; i += 16)
-        for (int j = tj; j < kp; j += 16)
-            fr.lmat[(size_t)i * fr.ldl + j] = (j < i) ? SP(i, j) : ((j == i) ? diag[i] : 0.0);
-    for (int j = tid; j < kp; j += 256) fr.yvec[j] = SP(kp, j);
-    // inverse of every 16x16 diagonal block of L (one thread per column)
-    if (tid < kp) {
-        const int b = tid >> 4, jc = tid & 15, r0 = b * EKF_RB;
-        double x[EKF_RB];
-#pragma unroll
-        for (int i = 0; i < EKF_RB; ++i) {
-            double sacc = 0.0;
-#pragma unroll
-            for (int c = 0; c < EKF_RB; ++c)
-                if (c >= jc && c < i) sacc += SP(r0 + i, r0 + c) * x[c];
-            const double inv = 1.0 / diag[r0 + i];
-            x[i] = (i < jc) ? 0.0 : ((i == jc) ? inv : -sacc * inv);
-        }
-#pragma unroll
-        for (int i = 0; i < EKF_RB; ++i) {
-            fr.dinv[(size_t)(r0 + i) * EKF_RB + jc] = x[i];
-            fr.dop[(size_t)(b * 4 + (jc >> 2)) * 64 + i + 16 * (jc & 3)] = x[i];
-        }
-    }
-    {   // -L blocks in MFMA A-operand order
-        const int nb = kp / EKF_RB;
-        const int total = nb * (nb - 1) / 2 * 256;
-        for (int e = tid; e < total; e += 256) {
-            const int lane = e & 63, r = (e >> 6) & 3, bq = e >> 8;
-            int b = 1;
-            while ((b + 1) * b / 2 <= bq) ++b;            // bq = b(b-1)/2 + q, q < b
-            const int q = bq - b * (b - 1) / 2;
-            fr.lop[e] = -SP(16 * b + (lane & 15), 16 * q + (lane >> 4) + 4 * r);
-        }
-    }
-#undef SP
-}
-
-// --------------------------------------------------------------------------
-// solve, fast path (kpad <= 128): blocked left-looking Cholesky, S dense in LDS.
-//   phase 1  all waves : block column b -= L[:, <b] L[b, <b]^T   (v_mfma_f64_16x16x4)
-//   phase 2  wave 0    : 16 pivots on up to 64 rows at once, lane = row, the 16
-//                        panel entries of a row in registers, pivot row broadcast
-//                        by v_readlane (no LDS, no barrier inside the chain)
-//   phase 3  waves 1-3 : rows beyond wave 0's 64: in-lane triangular solve
-// The residual rides along as row kp, so its factor row is y = L^-1 (z - h).
+// solve
 // --------------------------------------------------------------------------
 typedef double sf64x4 __attribute__((ext_vector_type(4)));
 
@@ -260,243 +195,6 @@ __device__ __forceinline__ double ekf_rsqrt_f64(double d) {
     return y;
 }
 
-int ekf_solve_blocked_lds_bytes(int kpad, int k) {
-    const size_t ldd = (size_t)kpad + 2;
-    return (int)((((size_t)kpad + 1) * ldd + (size_t)k * (EKF_CAM + EKF_JCOLS) + kpad + 4) * sizeof(double));
-}
-
-// -L blocks of block column p in MFMA operand order (see EkfFrame::lop); one wave.
-__device__ __forceinline__ void ekf_solve_emit_lop(const EkfFrame& fr, const double* S, int LD,
-                                                   int nb, int p, int lane) {
-    for (int i = p + 1; i < nb; ++i) {
-        const size_t base = (size_t)(i * (i - 1) / 2 + p) * 256;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            fr.lop[base + r * 64 + lane] =
-                -S[(EKF_RB * i + (lane & 15)) * LD + EKF_RB * p + (lane >> 4) + 4 * r];
-    }
-}
-
-// Left-looking update of one 16x16 block:  S[rows of block i][cb .. cb+15] -= sum_{q in [q0,q1)} L_iq L_bq^T
-// (b = cb / 16).  One wave; two independent MFMA chains.  Row block nb is the residual row (all 16
-// operand rows alias row kp, only row 0 is stored).
-__device__ __forceinline__ void ekf_solve_update_block(double* S, int LD, int kp, int i, int cb,
-                                                       int q0, int q1, int c, int g) {
-    const int rbase = EKF_RB * i;
-    const double* arow = S + (size_t)min(rbase + c, kp) * LD + g;
-    const double* brow = S + (size_t)(cb + c) * LD + g;
-    sf64x4 t, t2 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int r = 0; r < 4; ++r) t[r] = S[min(rbase + g + 4 * r, kp) * LD + cb + c];
-    int q = q0;
-    for (; q + 1 < q1; q += 2) {
-        double av[8], bv[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            av[r] = arow[EKF_RB * q + 4 * r];     // A[i = c][k = g + 4r]
-            bv[r] = brow[EKF_RB * q + 4 * r];     // B[k][j = c] = L[cb + c][k]
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            t = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[r], bv[r], t, 0, 0, 0);
-            t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[4 + r], bv[4 + r], t2, 0, 0, 0);
-        }
-    }
-    if (q < q1) {
-        double av[4], bv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { av[r] = arow[EKF_RB * q + 4 * r]; bv[r] = brow[EKF_RB * q + 4 * r]; }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) t = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[r], bv[r], t, 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = rbase + g + 4 * r;
-        if (row <= kp) S[row * LD + cb + c] = t[r] + t2[r];
-    }
-}
-
-// MS = 5: m <= 32 detections, MS = 6: m <= 64.  Pair p -> (row r1 = p >> MS, detection
-// jp = p & (2^MS - 1)); a thread's pairs all share jp (the block size is a multiple of 2^MS).
-#define EKF_SOLVE_THREADS 512
-template <int MS>
-__global__ __launch_bounds__(EKF_SOLVE_THREADS) void ekf_solve_blocked_kernel(EkfFrame fr) {
-    extern __shared__ __attribute__((aligned(16))) double b_sm[];
-    constexpr int NT = EKF_SOLVE_THREADS;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int c = lane & 15, g = lane >> 4;
-    const int k = fr.k, kp = fr.kpad, nb = kp / EKF_RB, LD = kp + 2, m = fr.m;
-    double* S = b_sm;                                   // [kp + 1][LD], row kp = residual
-    double* invd = S + (size_t)(kp + 1) * LD;           // [kp]  1 / L_jj
-    double* ac = invd + kp + 2;                         // [k][10]  A[:, 0:10]
-    double* hl = ac + (size_t)k * EKF_CAM;              // [k][13]
-    int nstamp = 0;
-#define EKF_STAMP() do { if (fr.stamps && tid == 0) fr.stamps[nstamp] = clock64(); ++nstamp; } while (0)
-    EKF_STAMP();
-    // ---- build S = A[:, support] H^T + R (lower triangle).
-    // asup (row stride LD) is copied flat into S with coalesced 16-byte loads; entry
-    // S[r1][3jp+d] is then computed in place from S[r1][3jp..3jp+2] = asup[r1][3jp..3jp+2].
-    constexpr int RSTEP = NT >> MS;                     // rows advanced per pair slot
-    constexpr int NPAIR = 128 / RSTEP;                  // pair slots: 128 rows per batch
-    const int jp = tid & ((1 << MS) - 1);
-    const bool jvalid = jp < m;
-    {
-        const int n16 = (k * LD) >> 1;                  // k * LD is even (LD even)
-        const double2* src = reinterpret_cast<const double2*>(fr.asup);
-        double2* dst = reinterpret_cast<double2*>(S);
-        constexpr int NV = 10;                          // 10 * 512 double2 = 10240 doubles >= 96 * 98
-        double2 v[NV];
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int e = tid + NT * i;
-            v[i] = src[min(e, n16 - 1)];
-        }
-        double acv[4], hv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = tid + NT * i, r = min(e >> 4, k - 1), cc = e & 15;
-            acv[i] = fr.amat[(int64_t)r * fr.lda + min(cc, EKF_CAM - 1)];
-            hv[i] = fr.jac[min(e, k * EKF_JLD - 1)];    // jac is [k][16], contiguous
-        }
-        const double rres = fr.resid[min(tid, k - 1)];
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int e = tid + NT * i;
-            if (e < n16) dst[e] = v[i];
-        }
-        for (int e = tid + NT * NV; e < n16; e += NT) dst[e] = src[e];   // (k * LD > 10240 doubles)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = tid + NT * i, r = e >> 4, cc = e & 15;
-            if (r < k && cc < EKF_CAM) ac[r * EKF_CAM + cc] = acv[i];
-            if (r < k && cc < EKF_JCOLS) hl[r * EKF_JCOLS + cc] = hv[i];
-        }
-        // padding rows k..kp-1 = identity, residual row kp
-        const int tr = tid >> 4, tc = tid & 15;
-        for (int r = k + tr; r <= kp; r += NT / 16) {
-            const int hi = (r < kp) ? (r | 15) : kp - 1;
-            for (int cc = tc; cc <= hi; cc += 16) S[r * LD + cc] = (r < kp && cc == r) ? 1.0 : 0.0;
-        }
-        __syncthreads();
-        EKF_STAMP();
-        if (tid < k) S[kp * LD + tid] = rres;
-    }
-    {
-        double hreg[3][EKF_JCOLS];                      // this thread's 3 Jacobian rows
-#pragma unroll
-        for (int d = 0; d < 3; ++d)
-#pragma unroll
-            for (int a = 0; a < EKF_JCOLS; ++a)
-                hreg[d][a] = hl[(3 * min(jp, m - 1) + d) * EKF_JCOLS + a];
-        for (int r0 = 0; r0 < k; r0 += 128) {           // one batch for k <= 128
-#pragma unroll
-            for (int u = 0; u < NPAIR; ++u) {
-                const int r1 = r0 + (tid >> MS) + RSTEP * u;
-                if (jvalid && r1 < k && r1 >= 3 * jp) {
-                    double* sp = S + r1 * LD + 3 * jp;
-                    const double a0 = sp[0], a1 = sp[1], a2 = sp[2];
-                    double a10[EKF_CAM];
-#pragma unroll
-                    for (int bb = 0; bb < EKF_CAM; ++bb) a10[bb] = ac[r1 * EKF_CAM + bb];
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) {
-                        const int r2 = 3 * jp + d;
-                        double acc = (r1 == r2) ? fr.nz.r_unc : 0.0;
-#pragma unroll
-                        for (int bb = 0; bb < EKF_CAM; ++bb) acc += a10[bb] * hreg[d][bb];
-                        acc += a0 * hreg[d][10] + a1 * hreg[d][11] + a2 * hreg[d][12];
-                        sp[d] = (r2 <= r1) ? acc : 0.0;   // strict upper part of a diagonal block = 0
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    EKF_STAMP();
-
-    // ---- blocked left-looking Cholesky.  8 waves:
-    //  (A) all waves : block column b -= L[:, b-1] L[b, b-1]^T  (the older terms were already applied)
-    //  (B) waves 0-2 : the 16-pivot chain of block b (lane = row, v_readlane broadcast)
-    //      waves 3-6 : meanwhile apply the finished block columns 0..b-1 to block column b+1
-    //      wave  7   : meanwhile emit the panel kernel's operands of block column b-1
-    int bad = 0;
-    for (int b = 0; b < nb; ++b) {
-        const int cb = EKF_RB * b;
-        if (b > 0) {
-            for (int i = b + wave; i <= nb; i += 8) ekf_solve_update_block(S, LD, kp, i, cb, b - 1, b, c, g);
-            __syncthreads();
-        }
-        EKF_STAMP();
-        //  wave 0 : rows cb .. cb+63
-        //  wave 1 : lanes 0-15 the diagonal rows again (every wave needs the pivot rows in its own
-        //           lanes), lanes 16-31 the rows of I_16 -- the same recurrence turns e_i into row i
-        //           of L_bb^-T, i.e. column i of Dinv_b, for free --, lanes 32-63 rows cb+64 .. cb+95
-        //  wave 2 : lanes 0-15 diagonal rows, lanes 16-63 rows cb+96 .. cb+143 (kp <= 128: enough)
-        const int xrow0 = (wave == 1) ? cb + 64 : cb + 96;
-        if (wave <= 1 || (wave == 2 && xrow0 <= kp)) {
-            int row;
-            if (wave == 0 || lane < EKF_RB) row = cb + lane;
-            else if (wave == 1) row = (lane < 32) ? -1 : xrow0 + (lane - 32);
-            else row = xrow0 + (lane - EKF_RB);
-            const bool ident = row < 0;
-            const bool store = !ident && (wave == 0 || lane >= EKF_RB) && row <= kp;
-            const double* src = S + (size_t)min(max(row, 0), kp) * LD + cb;
-            double a[EKF_RB], ys[EKF_RB];
-#pragma unroll
-            for (int x = 0; x < EKF_RB; ++x) a[x] = ident ? ((x == lane - EKF_RB) ? 1.0 : 0.0) : src[x];
-#pragma unroll
-            for (int j = 0; j < EKF_RB; ++j) {
-                const double d = ekf_readlane_f64(a[j], j);
-                bad |= !(d > 0.0);
-                const double y = ekf_rsqrt_f64(d);
-                ys[j] = y;
-                const double lj = a[j] * y;
-                a[j] = lj;
-#pragma unroll
-                for (int x = j + 1; x < EKF_RB; ++x) {
-                    const double lx = ekf_readlane_f64(lj, x);
-                    a[x] = __builtin_fma(-lj, lx, a[x]);
-                }
-            }
-            if (store) {
-                double* dst = S + (size_t)row * LD + cb;
-#pragma unroll
-                for (int x = 0; x < EKF_RB; ++x) dst[x] = a[x];
-            }
-            if (ident) {                                 // a[x] = Dinv_b[x][i], i = lane - 16
-                const int i = lane - EKF_RB;
-#pragma unroll
-                for (int x = 0; x < EKF_RB; ++x) {
-                    fr.dinv[(size_t)(cb + x) * EKF_RB + i] = a[x];
-                    fr.dop[(size_t)(b * 4 + (i >> 2)) * 64 + x + 16 * (i & 3)] = a[x];
-                }
-            }
-            if (tid == 0) {
-#pragma unroll
-                for (int j = 0; j < EKF_RB; ++j) invd[cb + j] = ys[j];
-            }
-        } else if (wave >= 3 && wave <= 6) {
-            if (b > 0 && b + 1 < nb)                     // rows of blocks b+1 .. nb (nb = residual row)
-                for (int i = b + 1 + (wave - 3); i <= nb; i += 4)
-                    ekf_solve_update_block(S, LD, kp, i, cb + EKF_RB, 0, b, c, g);
-        } else if (wave == 7 && b > 0) {
-            ekf_solve_emit_lop(fr, S, LD, nb, b - 1, lane);
-        }
-        __syncthreads();
-        EKF_STAMP();
-    }
-    if (bad && lane == 0) atomicOr(fr.status, 1);
-    // (block column nb-1 has no -L blocks below it)
-    for (int j = tid; j < kp; j += NT) fr.yvec[j] = S[kp * LD + j];
-    if (fr.wdbg) {                                      // dense L for tests only
-        for (int i = tid >> 4; i < kp; i += NT / 16)
-            for (int j = tid & 15; j < kp; j += 16)
-                fr.lmat[(size_t)i * fr.ldl + j] = (j <= i) ? S[i * LD + j] : 0.0;
-    }
-    EKF_STAMP();
-#undef EKF_STAMP
-}
-
 // --------------------------------------------------------------------------
 // solve, column-streaming blocked Cholesky (kpad <= 192).  16 waves, one workgroup.
 //   * only 4 block columns of S live in LDS (ring); a finished block column b is emitted from
@@ -506,9 +204,10 @@ __global__ __launch_bounds__(EKF_SOLVE_THREADS) void ekf_solve_blocked_kernel(Ek
 //                           (B) pivot waves: 16-pivot chain (lane = row, v_readlane broadcast),
 //                               one more wave carries the diagonal rows + I_16 -> Dinv_b;
 //                               every other wave meanwhile: column b+1 -= (q = b-1 term) and
-//                               column b+2 is BUILT (S = A_supp H^T + R from asupt, ac, hl) and gets
-//                               its q <= b-1 terms (lop for q <= b-2, LDS for q = b-1);
-//     so the S build and all but one update term per column hide behind the pivot chain.
+//                               column b+2 (fetched from `sblk` if it is not resident yet) gets
+//                               its q <= b-1 terms (LDS while column q is resident, else `lop`);
+//     so all but one update term per column hide behind the pivot chain.
+//   * S itself comes finished from the gather launch (`sblk`).
 //   * the residual rides along as row kp (its factor row is y = L^-1 (z - h)).
 // --------------------------------------------------------------------------
 #define SV_T 512
@@ -581,98 +280,69 @@ __device__ __forceinline__ void sv_terms_glb(SvAcc& a, const double* __restrict_
 
 // S entries of row block i of block column tc (rows 16i.., columns 16tc..): one wave, lane =
 // (row rr = lane & 15, column group cg = lane >> 4 -> 4 columns)
-struct SvBuild { double as[4][3]; double rs[4]; };
-// global loads of one block (branch-free, clamped) ...
-__device__ __forceinline__ void sv_build_load(const EkfFrame& fr, SvBuild& w, int kp, int nb, int i, int tc,
-                                              int lane) {
-    const int k = fr.k, rr = lane & 15, cg = lane >> 4;
-    const int r1c = min((i == nb) ? kp : EKF_RB * i + rr, k - 1);
-    const int r2b = EKF_RB * tc + 4 * cg;
+// One 16x16 block (row block i, block column tc) of S as the gather launch left it in `sblk`
+// ([block column][row][16], 2 KB contiguous per block): lane = (row rr = lane >> 2, 4 columns).
+// Row block nb is the residual row: z - h of the block column's 16 rows.
+__device__ __forceinline__ sf64x4 sv_fetch_block(const EkfFrame& fr, int kp, int nb, int i, int tc, int lane) {
+    const int rr = lane >> 2, cg = lane & 3;
+    sf64x4 v;
+    if (i < nb) {
+        const double* src = fr.sblk + ((size_t)tc * fr.sblk_rows + EKF_RB * i + rr) * 16 + 4 * cg;
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        const int r2c = min(r2b + x, k - 1);
-        const int jp = (r2c * 43691) >> 17;            // r2 / 3 for r2 < 98304
-        const double* ap = fr.asupt + (size_t)(3 * jp) * fr.ldast + r1c;
-        w.as[x][0] = ap[0];
-        w.as[x][1] = ap[fr.ldast];
-        w.as[x][2] = ap[2 * fr.ldast];
-        w.rs[x] = fr.resid[r2c];
+        for (int x = 0; x < 4; ++x) v[x] = src[x];
+    } else {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const int r2 = EKF_RB * tc + 4 * cg + x;
+            const double rv = fr.resid[min(r2, fr.k - 1)];
+            v[x] = (r2 < fr.k) ? rv : 0.0;
+        }
     }
+    return v;
 }
-// ... and the arithmetic: S entries of row block i of block column tc (rows 16i.., columns 16tc..);
-// one wave, lane = (row rr = lane & 15, column group cg = lane >> 4 -> 4 columns)
-__device__ __forceinline__ void sv_build_finish(const EkfFrame& fr, const SvBuild& w, double* tgt,
-                                                const double* ac, const double* hl, int kp, int nb, int i,
-                                                int tc, int lane) {
-    const int k = fr.k, rr = lane & 15, cg = lane >> 4;
-    const bool is_res = (i == nb);
-    if (is_res && rr != 0) return;                     // residual row block: one row
-    const int r1 = is_res ? kp : EKF_RB * i + rr;
-    const int r1c = min(r1, k - 1);
-    const int r2b = EKF_RB * tc + 4 * cg;
-    double a10[EKF_CAM];
+__device__ __forceinline__ void sv_put_block(const sf64x4& v, double* tgt, int kp, int nb, int i, int lane) {
+    const int rr = lane >> 2, cg = lane & 3;
+    if (i == nb && rr != 0) return;
+    const int row = (i < nb) ? EKF_RB * i + rr : kp;
 #pragma unroll
-    for (int bb = 0; bb < EKF_CAM; ++bb) a10[bb] = ac[r1c * EKF_CAM + bb];
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        const int r2 = r2b + x;
-        const double* h2 = hl + min(r2, k - 1) * EKF_JCOLS;
-        double acc = (r1 == r2) ? fr.nz.r_unc : 0.0;
-#pragma unroll
-        for (int bb = 0; bb < EKF_CAM; ++bb) acc += a10[bb] * h2[bb];
-        acc += w.as[x][0] * h2[10] + w.as[x][1] * h2[11] + w.as[x][2] * h2[12];
-        const bool pad = (r1 >= k) || (r2 >= k);       // identity padding rows / columns
-        double v = (r2 > r1) ? 0.0 : acc;              // strict upper part of a diagonal block
-        v = pad ? ((r1 == r2) ? 1.0 : 0.0) : v;
-        v = is_res ? ((r2 < k) ? w.rs[x] : 0.0) : v;
-        tgt[r1 * SV_CLD + 4 * cg + x] = v;
-    }
-}
-__device__ __forceinline__ void sv_build_block(const EkfFrame& fr, double* tgt, const double* ac,
-                                               const double* hl, int kp, int nb, int i, int tc, int lane) {
-    SvBuild w;
-    sv_build_load(fr, w, kp, nb, i, tc, lane);
-    sv_build_finish(fr, w, tgt, ac, hl, kp, nb, i, tc, lane);
+    for (int x = 0; x < 4; ++x) tgt[row * SV_CLD + 4 * cg + x] = v[x];
 }
 
-// number of block columns resident in LDS: all of them when they fit (kpad <= 112), else a ring
+// number of block columns resident in LDS: all of them when they fit (kpad <= 128), else a ring
 int ekf_solve_stream_ring(int kpad, int k) {
     const size_t col = (size_t)(kpad + 1) * SV_CLD * sizeof(double);
-    const size_t fixed = ((size_t)k * (EKF_CAM + EKF_JCOLS) + 8) * sizeof(double);
+    const size_t fixed = 8 * sizeof(double);
+    (void)k;
     int rs = (int)((160 * 1024 - fixed) / col);
     const int nb = kpad / EKF_RB;
     if (rs > nb) rs = nb;
     return rs < 4 ? 4 : rs;
 }
 int ekf_solve_stream_lds_bytes(int kpad, int k) {
-    return (int)(((size_t)ekf_solve_stream_ring(kpad, k) * (kpad + 1) * SV_CLD +
-                  (size_t)k * (EKF_CAM + EKF_JCOLS) + 8) * sizeof(double));
+    return (int)(((size_t)ekf_solve_stream_ring(kpad, k) * (kpad + 1) * SV_CLD + 8) * sizeof(double));
 }
 
 __global__ __launch_bounds__(SV_T) void ekf_solve_stream_kernel(EkfFrame fr, int RS) {
     extern __shared__ __attribute__((aligned(16))) double v_sm[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
-    const int k = fr.k, kp = fr.kpad, nb = kp / EKF_RB, rows = kp + 1;
+    const int kp = fr.kpad, nb = kp / EKF_RB, rows = kp + 1;
     // RS block columns live in LDS: all of them (RS == nb) or a ring (column c in slot c % RS,
     // overwritten when column c + RS is built, i.e. during iteration c + RS - 2)
     double* ring = v_sm;                                         // [RS][rows][SV_CLD]
-    double* ac = ring + (size_t)RS * rows * SV_CLD;              // [k][10]
     const bool all_resident = RS >= nb;
-    double* hl = ac + (size_t)k * EKF_CAM;                       // [k][13]
     auto colbuf = [&](int col) { return ring + (size_t)(col % RS) * rows * SV_CLD; };
     constexpr int NW = SV_T / 64;
     int nstamp = 0;
 #define EKF_STAMP() do { if (fr.stamps && tid == 0) fr.stamps[nstamp] = clock64(); ++nstamp; } while (0)
     EKF_STAMP();
-    // prologue.  Block columns built before the first pivot chain: all of them when they are all
-    // resident, else 0 and 1 (column c >= 2 is then built during iteration c - 2).  The global
-    // loads of this wave's first PB blocks are issued together with the ac / hl staging loads:
-    // one exposed memory round trip instead of one per block.
-    constexpr int PB = 5;
+    // prologue.  Block columns brought into LDS before the first pivot chain: all of them when
+    // they are all resident, else 0 and 1 (column c >= 2 then arrives during iteration c - 2).
+    // All loads of a wave's first PB blocks are issued together: one exposed memory round trip.
+    constexpr int PB = 6;
     const int ncol0 = all_resident ? nb : (nb > 1 ? 2 : 1);
     int ntot = 0;
     for (int tc = 0; tc < ncol0; ++tc) ntot += nb - tc + 1;
-    SvBuild pw[PB];
+    sf64x4 pv[PB];
     int pi[PB], ptc[PB];
 #pragma unroll
     for (int j = 0; j < PB; ++j) {
@@ -682,24 +352,16 @@ __global__ __launch_bounds__(SV_T) void ekf_solve_stream_kernel(EkfFrame fr, int
         while (u >= nb - tc + 1) { u -= nb - tc + 1; ++tc; }
         pi[j] = has ? tc + u : -1;
         ptc[j] = tc;
-        if (has) sv_build_load(fr, pw[j], kp, nb, pi[j], tc, lane);
+        pv[j] = sv_fetch_block(fr, kp, nb, has ? tc + u : 0, tc, lane);
     }
-    EKF_STAMP();
-    for (int e = tid; e < k * 16; e += SV_T) {
-        const int r = e >> 4, cc = e & 15;
-        if (cc < EKF_CAM) ac[r * EKF_CAM + cc] = fr.amat[(int64_t)r * fr.lda + cc];
-        if (cc < EKF_JCOLS) hl[r * EKF_JCOLS + cc] = fr.jac[e];
-    }
-    EKF_STAMP();
-    __syncthreads();
     EKF_STAMP();
 #pragma unroll
     for (int j = 0; j < PB; ++j)
-        if (pi[j] >= 0) sv_build_finish(fr, pw[j], colbuf(ptc[j]), ac, hl, kp, nb, pi[j], ptc[j], lane);
+        if (pi[j] >= 0) sv_put_block(pv[j], colbuf(ptc[j]), kp, nb, pi[j], lane);
     for (int u0 = wave + NW * PB; u0 < ntot; u0 += NW) {      // (more than PB blocks per wave: rare)
         int u = u0, tc = 0;
         while (u >= nb - tc + 1) { u -= nb - tc + 1; ++tc; }
-        sv_build_block(fr, colbuf(tc), ac, hl, kp, nb, tc + u, tc, lane);
+        sv_put_block(sv_fetch_block(fr, kp, nb, tc + u, tc, lane), colbuf(tc), kp, nb, tc + u, lane);
     }
     __syncthreads();
     EKF_STAMP();
@@ -784,12 +446,13 @@ __global__ __launch_bounds__(SV_T) void ekf_solve_stream_kernel(EkfFrame fr, int
                     sv_term_lds(a, colbuf(b - 1), kp, i, b + 1, c, g);
                     sv_acc_store(a, colbuf(b + 1), kp, i, c, g);
                 }
-            // block column b+2: built here unless it already is; then every finished term q <= b-1
+            // block column b+2: fetched here unless it already is resident; then every finished term q <= b-1
             // (from LDS while column q is still resident, else from the emitted -L blocks)
             const int tc = b + 2;
             if (tc < nb)
                 for (int i = tc + fw; i <= nb; i += nfw) {
-                    if (!all_resident) sv_build_block(fr, colbuf(tc), ac, hl, kp, nb, i, tc, lane);
+                    if (!all_resident)
+                        sv_put_block(sv_fetch_block(fr, kp, nb, i, tc, lane), colbuf(tc), kp, nb, i, lane);
                     if (b >= 1) {
                         SvAcc a;
                         sv_acc_load(a, colbuf(tc), kp, i, c, g);
@@ -812,34 +475,13 @@ __global__ __launch_bounds__(SV_T) void ekf_solve_stream_kernel(EkfFrame fr, int
 void ekf_launch_solve(const EkfFrame& fr, hipStream_t s) {
     static bool once = false;
     if (!once) {   // > 64 KB of dynamic LDS needs the opt-in
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ekf_solve_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ekf_solve_blocked_kernel<5>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ekf_solve_blocked_kernel<6>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ekf_solve_stream_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         once = true;
     }
-    static const bool old_path = getenv("EKF_SOLVE_OLD") != nullptr;
-    if (!old_path) {
-        static bool once2 = false;
-        if (!once2) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ekf_solve_stream_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            once2 = true;
-        }
-        hipLaunchKernelGGL(ekf_solve_stream_kernel, dim3(1), dim3(SV_T),
-                           ekf_solve_stream_lds_bytes(fr.kpad, fr.k), s, fr,
-                           ekf_solve_stream_ring(fr.kpad, fr.k));
-        return;
-    }
-    const int lds = ekf_solve_blocked_lds_bytes(fr.kpad, fr.k);
-    if (fr.kpad <= 128 && fr.m <= 32)
-        hipLaunchKernelGGL(ekf_solve_blocked_kernel<5>, dim3(1), dim3(EKF_SOLVE_THREADS), lds, s, fr);
-    else if (fr.kpad <= 128)
-        hipLaunchKernelGGL(ekf_solve_blocked_kernel<6>, dim3(1), dim3(EKF_SOLVE_THREADS), lds, s, fr);
-    else
-        hipLaunchKernelGGL(ekf_solve_kernel, dim3(1), dim3(256), ekf_solve_lds_bytes(fr.kpad), s, fr);
+    hipLaunchKernelGGL(ekf_solve_stream_kernel, dim3(1), dim3(SV_T),
+                       ekf_solve_stream_lds_bytes(fr.kpad, fr.k), s, fr,
+                       ekf_solve_stream_ring(fr.kpad, fr.k));
 }
 
 // --------------------------------------------------------------------------

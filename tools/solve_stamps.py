@@ -10,8 +10,8 @@ for ids,p in s.bootstrap(): f.observe(ids,p)
 for ids,p in s.steady(5): f.observe(ids,p)
 st=f.backend.debug_fetch("stamps",m)
 nb=6
-d=np.diff(st[:6+2*nb])
+d=np.diff(st[:4+2*nb])
 print("solve kernel phase stamps (shader cycles)")
-print("prologue: issue block loads", d[0], " stage ac/hl", d[1], " barrier", d[2], " finish blocks + barrier", d[3])
-for b in range(nb): print("b",b,"(A) last term",d[4+2*b],"(B) pivot chain",d[5+2*b])
-print("total", st[5+2*nb]-st[0])
+print("prologue: fetch S blocks", d[0], " put to LDS + barrier", d[1])
+for b in range(nb): print("b",b,"(A) last term",d[2+2*b],"(B) pivot chain",d[3+2*b])
+print("total", st[3+2*nb]-st[0])
