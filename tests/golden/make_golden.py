@@ -22,6 +22,9 @@ Fixtures written (inputs + the reference's outputs, data only):
   g4_scale_n1024.npz         n=1024, m=32: bootstrap + 3 frames, checksums
   g6_quaternion_rule.npz     SciPy's behaviour at the call site :138-149
   c1_detections.npz          the synthetic C1 replay itself (inputs only)
+  g5_rotations.npz           EKF_Rotations (ekf_with_rotations.py): h/dh lambdas on 128 random
+                             20-vectors, 120-frame 6-marker free run with full (state, P)
+                             snapshots before/after 10 of its steps
 """
 from __future__ import annotations
 
@@ -55,6 +58,57 @@ def load_reference():
     return EKF, TrajectoryWriter
 
 
+def golden_rotations():
+    """G5: the reference's EKF_Rotations (it caches its SymPy lambdas with dill under /tmp)."""
+    from filters.ekf_with_rotations import EKF_Rotations
+    init_pose = np.array([0, 0, 0, 1, 0, 0, 0, 0, 0, 0])
+    t0 = time.time()
+    flt = EKF_Rotations(init_pose)
+    print(f"reference EKF_Rotations ctor {time.time() - t0:.1f}s")
+    rng = np.random.default_rng(4321)
+    x = rng.normal(0.0, 1.0, size=(128, 20))
+    x[:, 7:10] = 0.0
+    x[:, 17:20] = 0.0
+    x[:64, 3:7] /= np.linalg.norm(x[:64, 3:7], axis=1, keepdims=True)
+    x[:64, 13:17] /= np.linalg.norm(x[:64, 13:17], axis=1, keepdims=True)
+    x[:, 10:13] = x[:, 0:3] + rng.normal(0.0, 5.0, size=(128, 3))
+    hv = np.stack([np.asarray(flt.h(list(r)), dtype=np.float64).reshape(7) for r in x])
+    dh = np.stack([np.asarray(flt.partial_jacobian(list(r)), dtype=np.float64) for r in x])
+    out = {"x": x, "h": hv, "dh": dh}
+    seq = small_sequence(frames=120, markers=6, max_visible=4, seed=3)
+    cat_ids, cat_poses, offs, has = [], [], [0], []
+    snaps = {1, 2, 5, 14, 15, 30, 47, 48, 90, 119}
+    hist = []
+    for f, (ts, ids, poses) in enumerate(seq):
+        has.append(ids is not None)
+        if ids is not None:
+            cat_ids.append(ids)
+            cat_poses.append(poses)
+            offs.append(offs[-1] + len(ids))
+            if f in snaps:
+                out[f"f{f}_state0"] = np.asarray(flt.state, dtype=np.float64).copy()
+                out[f"f{f}_P0"] = np.asarray(flt.uncertainty, dtype=np.float64).copy()
+                out[f"f{f}_lm_ids"] = np.asarray(
+                    [k for k, _ in sorted(flt.landmarks.items(), key=lambda kv: kv[1])], dtype=np.int64)
+            flt.observe(ids, poses)
+            if f in snaps:
+                out[f"f{f}_state1"] = np.asarray(flt.state, dtype=np.float64).copy()
+                out[f"f{f}_P1"] = np.asarray(flt.uncertainty, dtype=np.float64).copy()
+        else:
+            offs.append(offs[-1])
+        cam = np.zeros(10)
+        cam[:] = np.asarray(flt.state[:10], dtype=np.float64)
+        hist.append(cam[:7].copy())
+    out.update(frames=np.asarray(sorted(snaps)), ids=np.concatenate(cat_ids).astype(np.int32),
+               poses=np.concatenate(cat_poses), offsets=np.asarray(offs, dtype=np.int64),
+               has_detections=np.asarray(has), cam=np.stack(hist),
+               final_state=np.asarray(flt.state, dtype=np.float64),
+               final_P=np.asarray(flt.uncertainty, dtype=np.float64),
+               lm_ids=np.asarray([k for k, _ in sorted(flt.landmarks.items(), key=lambda kv: kv[1])]))
+    np.savez_compressed(HERE / "g5_rotations.npz", **out)
+    print("g5 done")
+
+
 # Seed of the C1 replay.  The as-written reference is chaotic (SURVEY F5): a
 # 1e-15 input perturbation reaches 1e-4 within 100-200 frames for every seed
 # tried (0..15); seed 6 has the longest horizon.  The fixture therefore also
@@ -66,6 +120,9 @@ C1_SEED = 6
 
 def main():
     ekf_cls, traj_writer_cls = load_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "g5":
+        golden_rotations()
+        return
     init_pose = np.array([0, 0, 0, 1, 0, 0, 0, 0, 0, 0])   # main/run_slam.py:85-88
 
     t0 = time.time()
@@ -199,6 +256,7 @@ def main():
         outs[i] = (dq * q).as_quat(scalar_first=True)
     np.savez_compressed(HERE / "g6_quaternion_rule.npz", q=qs, err=errs, out=outs)
     print("g6 done")
+    golden_rotations()
 
 
 if __name__ == "__main__":

@@ -109,3 +109,44 @@ def test_synthetic_stream_matches_fixture_inputs():
         assert np.array_equal(ids, g["ids"][f])
         assert np.allclose(poses[:, :3], g["z"][f], rtol=0, atol=1e-12)
         f += 1
+
+
+# ---------------------------------------------------------------------------
+# EKF_Rotations (ekf_with_rotations.py): G5
+# ---------------------------------------------------------------------------
+def test_g5_rotations_measurement_model_closed_form():
+    g = load_npz("g5_rotations.npz")
+    for x, h, dh in zip(g["x"], g["h"], g["dh"]):
+        assert np.abs(orc.h_rot_closed(x) - h).max() <= 1e-12 * max(1.0, np.abs(h).max())
+        assert np.abs(orc.dh_rot_closed(x) - dh).max() <= 1e-12 * max(1.0, np.abs(dh).max())
+
+
+@pytest.mark.parametrize("mode", ["reference_ops", "fast"])
+def test_g5_rotations_teacher_forced_steps(mode):
+    g = load_npz("g5_rotations.npz")
+    offs = g["offsets"]
+    for f in g["frames"]:
+        flt = orc.OracleEKFRotations(INIT, mode=mode)
+        _restore(flt, g[f"f{f}_state0"], g[f"f{f}_P0"], g[f"f{f}_lm_ids"])
+        sl = slice(offs[f], offs[f + 1])
+        flt.observe(list(g["ids"][sl]), g["poses"][sl])
+        assert flt.state.shape == g[f"f{f}_state1"].shape
+        assert rel_err(flt.state, g[f"f{f}_state1"]) <= 1e-11, f
+        assert rel_err(flt.uncertainty, g[f"f{f}_P1"]) <= 1e-11, f
+
+
+@pytest.mark.parametrize("mode", ["reference_ops", "fast"])
+def test_g5_rotations_free_run_120_frames(mode):
+    """This variant uses the consistent quaternion convention: not chaotic, the whole run matches."""
+    g = load_npz("g5_rotations.npz")
+    offs = g["offsets"]
+    flt = orc.OracleEKFRotations(INIT, mode=mode)
+    cams = []
+    for f in range(len(g["has_detections"])):
+        if g["has_detections"][f]:
+            sl = slice(offs[f], offs[f + 1])
+            flt.observe(list(g["ids"][sl]), g["poses"][sl])
+        cams.append(np.asarray(flt.state[:7], dtype=np.float64).copy())
+    assert rel_err(np.stack(cams), g["cam"]) <= 1e-9
+    assert rel_err(flt.state, g["final_state"]) <= 1e-9
+    assert rel_err(flt.uncertainty, g["final_P"]) <= 1e-9
