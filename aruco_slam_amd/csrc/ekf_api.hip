@@ -38,16 +38,19 @@ constexpr int kEventPool = 2048;  // frames of timing events kept before folding
 
 struct Layout {
     int64_t cap;      // padded state dimension (multiple of 128)
-    int kmax;         // 3 * max_visible rounded up to 16
+    int rd, lmd;      // rows per detection, landmark dims (model)
+    int kmax;         // rd * max_visible rounded up to 16
     size_t elem;      // sizeof(cov element)
     size_t off_jac, off_resid, off_y, off_lmcol, off_amat, off_sblk, off_lmat, off_dinv, off_lop, off_dop, off_wpanel, off_wpanel2, off_prow, off_wdbg,
-        off_idx, off_z, off_status, off_stamps, off_diag, off_xyz, off_unc, total;
+        off_idx, off_z, off_status, off_stamps, off_dx, off_diag, off_xyz, off_unc, total;
 };
 
 Layout make_layout(const ekf_config& c) {
     Layout L{};
-    L.cap = round_up((int64_t)3 * c.max_landmarks + EKF_CAM, 128);
-    L.kmax = (int)round_up(3 * c.max_visible, EKF_RB);
+    L.rd = c.model == EKF_MODEL_ROTATIONS ? 7 : 3;
+    L.lmd = c.model == EKF_MODEL_ROTATIONS ? 10 : 3;
+    L.cap = round_up((int64_t)L.lmd * c.max_landmarks + EKF_CAM, 128);
+    L.kmax = (int)round_up(L.rd * c.max_visible, EKF_RB);
     L.elem = c.cov_dtype == EKF_COV_F32 ? 4 : 8;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += align256(bytes); return at; };
@@ -66,15 +69,16 @@ Layout make_layout(const ekf_config& c) {
     }
     L.off_wpanel = take((size_t)L.kmax * L.cap * L.elem);
     L.off_wpanel2 = take((size_t)L.kmax * L.cap * L.elem);
-    L.off_prow = take((size_t)(EKF_CAM + 3 * c.max_visible) * L.cap * L.elem);
+    L.off_prow = take((size_t)(EKF_CAM + L.lmd * c.max_visible) * L.cap * L.elem);
     L.off_wdbg = take((size_t)L.kmax * L.cap * 8);
     L.off_idx = take((size_t)c.max_visible * 4);
-    L.off_z = take((size_t)c.max_visible * 3 * 8);
+    L.off_z = take((size_t)c.max_visible * 7 * 8);
     L.off_status = take(256);
     L.off_stamps = take(64 * 8);
+    L.off_dx = take((size_t)L.cap * 8);
     L.off_diag = take((size_t)L.cap * 8);
-    L.off_xyz = take((size_t)256 * 3 * 8);
-    L.off_unc = take((size_t)256 * 3 * 8);
+    L.off_xyz = take((size_t)256 * 6 * 8);
+    L.off_unc = take((size_t)256 * 10 * 8);
     L.total = o;
     return L;
 }
@@ -82,8 +86,10 @@ Layout make_layout(const ekf_config& c) {
 int check_config(const ekf_config* c) {
     if (!c) return fail(EKF_ERR_INVALID, "config is NULL");
     if (c->max_landmarks < 1) return fail(EKF_ERR_INVALID, "max_landmarks must be >= 1");
-    if (c->max_visible < 1 || c->max_visible > 64)
-        return fail(EKF_ERR_INVALID, "max_visible must be in 1..64");
+    if (c->model != EKF_MODEL_EKF && c->model != EKF_MODEL_ROTATIONS)
+        return fail(EKF_ERR_INVALID, "unknown model");
+    if (c->max_visible < 1 || c->max_visible > (c->model == EKF_MODEL_ROTATIONS ? 27 : 64))
+        return fail(EKF_ERR_INVALID, "max_visible must be in 1..64 (1..27 for EKF_MODEL_ROTATIONS)");
     if (c->cov_dtype != EKF_COV_F64 && c->cov_dtype != EKF_COV_F32)
         return fail(EKF_ERR_INVALID, "cov_dtype must be EKF_COV_F64 or EKF_COV_F32");
     if (c->quat_mode != EKF_QUAT_AS_WRITTEN && c->quat_mode != EKF_QUAT_SCALAR_FIRST)
@@ -124,7 +130,7 @@ struct ekf_filter {
     double t_sum_us[kTimedKernels] = {};
     int64_t t_cnt[kTimedKernels] = {};
 
-    int dims() const { return 3 * n_lm + EKF_CAM; }
+    int dims() const { return lay.lmd * n_lm + EKF_CAM; }
     template <typename P> P* at(size_t off) const { return reinterpret_cast<P*>(ws + off); }
 };
 
@@ -153,10 +159,11 @@ EkfFrame make_frame(ekf_filter* f, const int32_t* idx_dev, const double* z_dev, 
     fr.cov = f->cov;
     fr.ld = f->ld;
     fr.state = f->state;
+    fr.model = f->cfg.model;
     fr.dims = f->dims();
     fr.ncols = (int)round_up(fr.dims, 128);
     fr.m = m;
-    fr.k = 3 * m;
+    fr.k = L.rd * m;
     fr.kpad = (int)round_up(fr.k, EKF_RB);
     fr.idx = idx_dev;
     fr.z = z_dev;
@@ -178,6 +185,7 @@ EkfFrame make_frame(ekf_filter* f, const int32_t* idx_dev, const double* z_dev, 
     fr.wdbg = f->debug_w ? f->at<double>(L.off_wdbg) : nullptr;
     fr.status = f->at<int32_t>(L.off_status);
     fr.traj_row = traj_row;
+    fr.dxvec = f->at<double>(L.off_dx);
     fr.stamps = f->debug_w ? f->at<long long>(L.off_stamps) : nullptr;
     fr.nz = EkfNoise{f->cfg.q_cam, f->cfg.q_err, f->cfg.q_lm, f->cfg.r_uncertainty};
     fr.quat_mode = f->cfg.quat_mode;
@@ -206,6 +214,7 @@ int enqueue_frame(ekf_filter* f, const int32_t* idx_dev, const double* z_dev, in
     ekf_launch_solve(fr, f->stream);
     if (ev_all) HIP_TRY(hipEventRecord(ev[2], f->stream));
     if (f32) ekf_launch_panel<float>(fr, f->stream); else ekf_launch_panel<double>(fr, f->stream);
+    if (fr.model == 1) ekf_launch_inject_rot(fr, f->n_lm, f->stream);
     if (ev) HIP_TRY(hipEventRecord(ev[3], f->stream));
     if (f32) ekf_launch_cov_update<float>(fr, variant, f->stream);
     else ekf_launch_cov_update<double>(fr, variant, f->stream);
@@ -247,6 +256,7 @@ int ekf_default_config(ekf_config* cfg) {
     cfg->cov_dtype = EKF_COV_F64;
     cfg->quat_mode = EKF_QUAT_AS_WRITTEN;
     cfg->cov_kernel = EKF_COVK_AUTO;
+    cfg->model = EKF_MODEL_EKF;
     cfg->initial_camera_uncertainty = 0.1;
     cfg->initial_landmark_uncertainty = 0.7;
     cfg->r_uncertainty = 0.9;
@@ -281,8 +291,8 @@ int ekf_create(const ekf_config* cfg, ekf_filter** out) {
     f->cfg = *cfg;
     f->lay = make_layout(*cfg);
     f->stream = static_cast<hipStream_t>(cfg->stream);
-    f->slot_bytes = align256((size_t)cfg->max_visible * 4) + align256((size_t)cfg->max_visible * 24);
-    if (f->slot_bytes < align256(256 * 24) * 2) f->slot_bytes = align256(256 * 24) * 2;
+    f->slot_bytes = align256((size_t)cfg->max_visible * 4) + align256((size_t)cfg->max_visible * 56);
+    if (f->slot_bytes < align256(256 * 48) + align256(256 * 80)) f->slot_bytes = align256(256 * 48) + align256(256 * 80);
     hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&f->pinned), f->slot_bytes * kStageSlots,
                                  hipHostMallocDefault);
     if (e != hipSuccess) {
@@ -387,16 +397,25 @@ int ekf_add_markers(ekf_filter* f, const double* cam_frame_xyz, const double* di
         char* slot = f->pinned + (size_t)f->slot * f->slot_bytes;
         HIP_TRY(hipEventSynchronize(f->slot_done[f->slot]));
         double* hx = reinterpret_cast<double*>(slot);
-        double* hu = reinterpret_cast<double*>(slot + align256(256 * 24));
-        std::memcpy(hx, cam_frame_xyz + 3 * done, (size_t)chunk * 24);
-        if (diag_uncertainty) std::memcpy(hu, diag_uncertainty + 3 * done, (size_t)chunk * 24);
-        HIP_TRY(hipMemcpyAsync(f->at<double>(L.off_xyz), hx, (size_t)chunk * 24, hipMemcpyHostToDevice,
+        double* hu = reinterpret_cast<double*>(slot + align256(256 * 48));
+        const bool rot = f->cfg.model == EKF_MODEL_ROTATIONS;
+        const size_t pb = rot ? 48 : 24, ub = rot ? 80 : 24;      // bytes per marker: pose / variances
+        std::memcpy(hx, cam_frame_xyz + (pb / 8) * done, (size_t)chunk * pb);
+        if (diag_uncertainty) std::memcpy(hu, diag_uncertainty + (ub / 8) * done, (size_t)chunk * ub);
+        HIP_TRY(hipMemcpyAsync(f->at<double>(L.off_xyz), hx, (size_t)chunk * pb, hipMemcpyHostToDevice,
                                f->stream));
         if (diag_uncertainty)
-            HIP_TRY(hipMemcpyAsync(f->at<double>(L.off_unc), hu, (size_t)chunk * 24,
+            HIP_TRY(hipMemcpyAsync(f->at<double>(L.off_unc), hu, (size_t)chunk * ub,
                                    hipMemcpyHostToDevice, f->stream));
         const double* unc_dev = diag_uncertainty ? f->at<double>(L.off_unc) : nullptr;
-        if (L.elem == 4)
+        if (rot) {
+            if (L.elem == 4)
+                ekf_launch_add_markers_rot<float>(f->cov, f->ld, f->state, f->dims(), f->at<double>(L.off_xyz),
+                                                  unc_dev, f->cfg.initial_landmark_uncertainty, chunk, f->stream);
+            else
+                ekf_launch_add_markers_rot<double>(f->cov, f->ld, f->state, f->dims(), f->at<double>(L.off_xyz),
+                                                   unc_dev, f->cfg.initial_landmark_uncertainty, chunk, f->stream);
+        } else if (L.elem == 4)
             ekf_launch_add_markers<float>(f->cov, f->ld, f->state, f->dims(), f->at<double>(L.off_xyz),
                                           unc_dev, f->cfg.initial_landmark_uncertainty, chunk, f->stream);
         else
@@ -426,12 +445,12 @@ int ekf_observe(ekf_filter* f, const int32_t* lm_index, const double* z, int32_t
     HIP_TRY(hipEventSynchronize(f->slot_done[f->slot]));
     int32_t* hidx = reinterpret_cast<int32_t*>(slot);
     double* hz = reinterpret_cast<double*>(slot + align256((size_t)f->cfg.max_visible * 4));
+    const size_t zb = (size_t)m * L.rd * 8;
     std::memcpy(hidx, lm_index, (size_t)m * 4);
-    std::memcpy(hz, z, (size_t)m * 24);
+    std::memcpy(hz, z, zb);
     HIP_TRY(hipMemcpyAsync(f->at<int32_t>(L.off_idx), hidx, (size_t)m * 4, hipMemcpyHostToDevice,
                            f->stream));
-    HIP_TRY(hipMemcpyAsync(f->at<double>(L.off_z), hz, (size_t)m * 24, hipMemcpyHostToDevice,
-                           f->stream));
+    HIP_TRY(hipMemcpyAsync(f->at<double>(L.off_z), hz, zb, hipMemcpyHostToDevice, f->stream));
     rc = enqueue_frame(f, f->at<int32_t>(L.off_idx), f->at<double>(L.off_z), m, nullptr);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(f->slot_done[f->slot], f->stream));
@@ -461,7 +480,7 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
     const bool lookahead = want && !f->timing && frames >= 2;
     if (!lookahead) {
         for (int t = 0; t < frames; ++t) {
-            rc = enqueue_frame(f, lm_index_dev + (size_t)t * m, z_dev + (size_t)t * m * 3, m,
+            rc = enqueue_frame(f, lm_index_dev + (size_t)t * m, z_dev + (size_t)t * m * f->lay.rd, m,
                                trajectory_dev ? trajectory_dev + (size_t)t * 7 : nullptr);
             if (rc) return rc;
         }
@@ -477,13 +496,14 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
     void* prow = f->at<void>(L.off_prow);
     for (int t = 0; t < frames; ++t) {
         const int par = t & 1;
-        EkfFrame fr = make_frame(f, lm_index_dev + (size_t)t * m, z_dev + (size_t)t * m * 3, m,
+        EkfFrame fr = make_frame(f, lm_index_dev + (size_t)t * m, z_dev + (size_t)t * m * L.rd, m,
                                  trajectory_dev ? trajectory_dev + (size_t)t * 7 : nullptr);
         fr.wpanel = wbuf[par];
         fr.prow = (t > 0) ? prow : nullptr;
         if (f32) ekf_launch_gather<float>(fr, f->stream); else ekf_launch_gather<double>(fr, f->stream);
         ekf_launch_solve(fr, f->stream);
         if (f32) ekf_launch_panel<float>(fr, f->stream); else ekf_launch_panel<double>(fr, f->stream);
+        if (fr.model == 1) ekf_launch_inject_rot(fr, f->n_lm, f->stream);
         if (t + 1 < frames) {
             // the rows below are read from P_t: the big update of frame t-1 must be complete
             // (this also frees the W panel that frame t+1 will overwrite)
@@ -543,7 +563,7 @@ int ekf_get_cov_diag(ekf_filter* f, double* out, int32_t count) {
 int ekf_get_cov(ekf_filter* f, double* out, int32_t dims) {
     int rc = check_ready(f);
     if (rc) return rc;
-    if (!out || dims != f->dims()) return fail(EKF_ERR_INVALID, "dims must equal 3*num_landmarks+10");
+    if (!out || dims != f->dims()) return fail(EKF_ERR_INVALID, "dims must equal the state dimension");
     rc = sync_and_check(f);
     if (rc) return rc;
     const size_t el = f->lay.elem;
@@ -567,7 +587,7 @@ int ekf_set_state(ekf_filter* f, const double* state, int32_t num_landmarks) {
         return fail(EKF_ERR_CAPACITY, "more landmarks than max_landmarks");
     HIP_TRY(hipStreamSynchronize(f->stream));
     HIP_TRY(hipMemset(f->state, 0, (size_t)f->lay.cap * 8));
-    HIP_TRY(hipMemcpy(f->state, state, (size_t)(3 * num_landmarks + EKF_CAM) * 8,
+    HIP_TRY(hipMemcpy(f->state, state, (size_t)(f->lay.lmd * num_landmarks + EKF_CAM) * 8,
                       hipMemcpyHostToDevice));
     f->n_lm = num_landmarks;
     return EKF_OK;
@@ -577,7 +597,7 @@ int ekf_set_cov(ekf_filter* f, const double* cov, int32_t dims) {
     int rc = check_ready(f);
     if (rc) return rc;
     if (!cov || dims != f->dims())
-        return fail(EKF_ERR_INVALID, "dims must equal 3*num_landmarks+10 (call ekf_set_state first)");
+        return fail(EKF_ERR_INVALID, "dims must equal the state dimension (call ekf_set_state first)");
     const Layout& L = f->lay;
     HIP_TRY(hipStreamSynchronize(f->stream));
     HIP_TRY(hipMemset(f->cov, 0, (size_t)L.cap * L.cap * L.elem));
@@ -637,12 +657,13 @@ int ekf_debug_fetch(ekf_filter* f, int32_t what, double* out, size_t count) {
         return EKF_OK;
     }
     const Layout& L = f->lay;
-    const int k = 3 * f->last_m, kp = (int)round_up(k, EKF_RB), dims = f->dims();
+    const int k = L.rd * f->last_m, kp = (int)round_up(k, EKF_RB), dims = f->dims();
+    const int jc = f->cfg.model == EKF_MODEL_ROTATIONS ? 20 : EKF_JCOLS;
     HIP_TRY(hipStreamSynchronize(f->stream));
     switch (what) {
         case 0:
-            if (count < (size_t)k * EKF_JCOLS) return fail(EKF_ERR_INVALID, "out too small");
-            HIP_TRY(hipMemcpy2D(out, EKF_JCOLS * 8, f->at<double>(L.off_jac), EKF_JLD * 8, EKF_JCOLS * 8,
+            if (count < (size_t)k * jc) return fail(EKF_ERR_INVALID, "out too small");
+            HIP_TRY(hipMemcpy2D(out, (size_t)jc * 8, f->at<double>(L.off_jac), EKF_JLD * 8, (size_t)jc * 8,
                                 k, hipMemcpyDeviceToHost));
             return EKF_OK;
         case 1:

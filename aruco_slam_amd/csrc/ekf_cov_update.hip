@@ -256,8 +256,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void ekf_cov_rows_kernel(EkfFrame fr) {
     __shared__ T wr[192];                            // -W[:, row]
     const int slot = blockIdx.x;
+    const int lmd = fr.model == 1 ? 10 : EKF_LM;     // state dims per landmark
     const int row = (slot < EKF_CAM) ? slot
-                                     : EKF_CAM + EKF_LM * fr.next_idx[(slot - EKF_CAM) / 3] + (slot - EKF_CAM) % 3;
+                                     : EKF_CAM + lmd * fr.next_idx[(slot - EKF_CAM) / lmd] + (slot - EKF_CAM) % lmd;
     const T* __restrict__ wp = static_cast<const T*>(fr.wpanel);
     const T* __restrict__ P = static_cast<const T*>(fr.cov);
     T* __restrict__ out = static_cast<T*>(fr.prow_out);
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(256) void ekf_cov_rows_kernel(EkfFrame fr) {
 template <typename T>
 void ekf_launch_cov_rows(const EkfFrame& fr, hipStream_t s) {
     const int chunks = (fr.ncols + 255) / 256;      // one column per thread
-    hipLaunchKernelGGL(ekf_cov_rows_kernel<T>, dim3(EKF_CAM + 3 * fr.next_m, chunks), dim3(256), 0, s, fr);
+    hipLaunchKernelGGL(ekf_cov_rows_kernel<T>, dim3(EKF_CAM + (fr.model == 1 ? 10 : EKF_LM) * fr.next_m, chunks), dim3(256), 0, s, fr);
 }
 template void ekf_launch_cov_rows<float>(const EkfFrame&, hipStream_t);
 template void ekf_launch_cov_rows<double>(const EkfFrame&, hipStream_t);

@@ -9,7 +9,8 @@ struct EkfFrame {
     void* cov;             // P, f32 or f64, row-major, leading dim ld
     int64_t ld;
     double* state;         // [cap]
-    int32_t dims;          // N = 3 n + 10
+    int32_t model;         // 0 = EKF, 1 = EKF_Rotations (see EkfModel in ekf_device.h)
+    int32_t dims;          // N = lmd n + 10
     int32_t ncols;         // N rounded up to 128 (<= ld): columns the panel covers
     int32_t m;             // detections this frame
     int32_t k;             // 3 m
@@ -39,6 +40,7 @@ struct EkfFrame {
     double* wdbg;          // optional f64 copy of W for tests (may be null)
     int32_t* status;       // [0] != 0 -> non-SPD innovation covariance seen
     double* traj_row;      // optional: state[0:7] after the update
+    double* dxvec;         // model 1: dx = W^T y for every state dimension (input of the injection kernel)
     long long* stamps;     // optional: s_memtime stamps of the solve kernel's phases (diagnostics)
     // cross-frame lookahead (sequence mode).  After the panel kernel of frame t, ekf_launch_cov_rows
     // computes the rows of P_{t+1} that frame t+1's gather will read (camera rows 0..9 and the 3
@@ -63,5 +65,9 @@ template <typename T>
 void ekf_launch_add_markers(void* cov, int64_t ld, double* state, int32_t dims,
                             const double* xyz_dev, const double* unc_dev, double default_unc,
                             int32_t count, hipStream_t s);
+void ekf_launch_inject_rot(const EkfFrame& fr, int n_lm, hipStream_t s);
+template <typename T>
+void ekf_launch_add_markers_rot(void* cov, int64_t ld, double* state, int32_t dims, const double* pose6_dev,
+                                const double* unc_dev, double default_unc, int32_t count, hipStream_t s);
 template <typename T>
 void ekf_launch_cov_diag(const void* cov, int64_t ld, double* out_dev, int32_t count, hipStream_t s);

@@ -24,12 +24,14 @@
 //                            solve kernel keeps in LDS.  S does not wait for A, so the single
 //                            workgroup solve kernel starts from a finished S.
 // Both first evaluate h / dh for every detection (one thread each) into LDS.
-template <typename T, int NU>
+template <typename T, int NU, int MODEL>
 __global__ __launch_bounds__(256) void ekf_gather_kernel(EkfFrame fr) {
+    constexpr int RD = EkfModel<MODEL>::RD, LMD = EkfModel<MODEL>::LMD, JC = EkfModel<MODEL>::JC;
+    constexpr int NSLOT = EKF_CAM + LMD * EkfModel<MODEL>::NDET16;   // P rows one S block can touch
     extern __shared__ __attribute__((aligned(16))) double g_sm[];
-    double* hs = g_sm;                                  // [k][13]
-    double* us = g_sm + fr.k * EKF_JCOLS;               // [31][16]  (S blocks only)
-    int* lmc = reinterpret_cast<int*>(us + 31 * 16);
+    double* hs = g_sm;                                  // [k][JC]
+    double* us = g_sm + fr.k * JC;                      // [NSLOT][16]  (S blocks only)
+    int* lmc = reinterpret_cast<int*>(us + NSLOT * 16);
     const int tid = threadIdx.x;
     const int m = fr.m, k = fr.k;
     const int nchunk = fr.ncols / 64;
@@ -50,30 +52,30 @@ __global__ __launch_bounds__(256) void ekf_gather_kernel(EkfFrame fr) {
     double cam[EKF_CAM];
 #pragma unroll
     for (int a = 0; a < EKF_CAM; ++a) cam[a] = fr.state[a];
-    if (tid < m) lmc[tid] = EKF_CAM + EKF_LM * fr.idx[tid];
+    if (tid < m) lmc[tid] = EKF_CAM + LMD * fr.idx[tid];
     __syncthreads();
     // landmark rows of P for this wave's detections (A chunks)
-    T plr[NU][3];
+    T plr[NU][LMD];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         const int ju = min(g + 4 * u, m - 1);
         const int c0 = lmc[ju];
 #pragma unroll
-        for (int d = 0; d < 3; ++d)
-            plr[u][d] = prow ? prow[(int64_t)(EKF_CAM + 3 * ju + d) * fr.ldw + c] : P[(int64_t)(c0 + d) * ld + c];
+        for (int d = 0; d < LMD; ++d)
+            plr[u][d] = prow ? prow[(int64_t)(EKF_CAM + LMD * ju + d) * fr.ldw + c] : P[(int64_t)(c0 + d) * ld + c];
     }
     if (tid < m) {
         const int c0 = lmc[tid];
-        double lm[3], h[3], J[3][EKF_JCOLS];
-        for (int d = 0; d < 3; ++d) lm[d] = fr.state[c0 + d];
-        ekf_measure(cam, lm, h, J);
-        for (int d = 0; d < 3; ++d)
-            for (int a = 0; a < EKF_JCOLS; ++a) hs[(3 * tid + d) * EKF_JCOLS + a] = J[d][a];
+        double lm[LMD], h[RD], J[RD][JC];
+        for (int d = 0; d < LMD; ++d) lm[d] = fr.state[c0 + d];
+        ekf_measure_model<MODEL>(cam, lm, h, J);
+        for (int d = 0; d < RD; ++d)
+            for (int a = 0; a < JC; ++a) hs[(RD * tid + d) * JC + a] = J[d][a];
         if (blockIdx.x == 0) {
-            for (int d = 0; d < 3; ++d) {
-                for (int a = 0; a < EKF_JCOLS; ++a)
-                    fr.jac[(size_t)(3 * tid + d) * EKF_JLD + a] = J[d][a];
-                fr.resid[3 * tid + d] = fr.z[3 * tid + d] - h[d];
+            for (int d = 0; d < RD; ++d) {
+                for (int a = 0; a < JC; ++a)
+                    fr.jac[(size_t)(RD * tid + d) * EKF_JLD + a] = J[d][a];
+                fr.resid[RD * tid + d] = fr.z[RD * tid + d] - h[d];   // additive residual, also on q_cl (:140)
             }
             fr.lmcol[tid] = c0;
         }
@@ -84,26 +86,26 @@ __global__ __launch_bounds__(256) void ekf_gather_kernel(EkfFrame fr) {
         int sb = blockIdx.x - nchunk, bi = 0;
         while (sb > bi) { sb -= bi + 1; ++bi; }
         const int bj = sb;
-        const int j0 = (16 * bi) / 3;                  // first detection that touches the block's rows
+        const int j0 = (16 * bi) / RD;                 // first detection that touches the block's rows
         // U[slot][c2] = sum_b Pq[rho(slot)][col(r2, b)] H[r2][b]; rho: slots 0..9 camera rows, slot
-        // 10 + 3 (j - j0) + d row d of detection j (<= 7 detections touch 16 rows)
-        for (int e = tid; e < 31 * 16; e += 256) {
+        // 10 + LMD (j - j0) + d row d of detection j (<= NDET16 detections touch 16 rows)
+        for (int e = tid; e < NSLOT * 16; e += 256) {
             const int slot = e >> 4, c2 = e & 15, r2 = 16 * bj + c2;
-            const int j = j0 + (slot - EKF_CAM) / 3, d = (slot - EKF_CAM) % 3;
+            const int j = j0 + (slot - EKF_CAM) / LMD, d = (slot - EKF_CAM) % LMD;
             double acc = 0.0;
             if (r2 < k && (slot < EKF_CAM || j < m)) {
                 const int rho = (slot < EKF_CAM) ? slot : lmc[j] + d;
-                const T* prw = prow ? prow + (int64_t)((slot < EKF_CAM) ? slot : EKF_CAM + 3 * j + d) * fr.ldw
+                const T* prw = prow ? prow + (int64_t)((slot < EKF_CAM) ? slot : EKF_CAM + LMD * j + d) * fr.ldw
                                     : P + (int64_t)rho * ld;
-                const double* h2 = hs + r2 * EKF_JCOLS;
-                const int c20 = lmc[r2 / 3];
-                T pv[EKF_JCOLS];
+                const double* h2 = hs + r2 * JC;
+                const int c20 = lmc[r2 / RD];
+                T pv[JC];
 #pragma unroll
                 for (int b = 0; b < EKF_CAM; ++b) pv[b] = prw[b];
 #pragma unroll
-                for (int b = 0; b < 3; ++b) pv[EKF_CAM + b] = prw[c20 + b];
+                for (int b = 0; b < LMD; ++b) pv[EKF_CAM + b] = prw[c20 + b];
 #pragma unroll
-                for (int b = 0; b < EKF_JCOLS; ++b) {
+                for (int b = 0; b < JC; ++b) {
                     const int col = (b < EKF_CAM) ? b : c20 + (b - EKF_CAM);
                     const double pq = (double)pv[b] + ((col == rho) ? ekf_qdiag(rho, fr.dims, fr.nz) : 0.0);
                     acc += pq * h2[b];
@@ -120,13 +122,13 @@ __global__ __launch_bounds__(256) void ekf_gather_kernel(EkfFrame fr) {
             } else if (r2 > r1) {
                 v = 0.0;                               // strict upper part of a diagonal block
             } else {
-                const double* h1 = hs + r1 * EKF_JCOLS;
-                const int s1 = EKF_CAM + 3 * (r1 / 3 - j0);
+                const double* h1 = hs + r1 * JC;
+                const int s1 = EKF_CAM + LMD * (r1 / RD - j0);
                 double acc = (r1 == r2) ? fr.nz.r_unc : 0.0;
 #pragma unroll
                 for (int a = 0; a < EKF_CAM; ++a) acc += h1[a] * us[a * 16 + c2];
 #pragma unroll
-                for (int d = 0; d < 3; ++d) acc += h1[EKF_CAM + d] * us[(s1 + d) * 16 + c2];
+                for (int d = 0; d < LMD; ++d) acc += h1[EKF_CAM + d] * us[(s1 + d) * 16 + c2];
                 v = acc;
             }
             fr.sblk[((size_t)bj * fr.sblk_rows + r1) * 16 + c2] = v;
@@ -141,18 +143,18 @@ __global__ __launch_bounds__(256) void ekf_gather_kernel(EkfFrame fr) {
         const int j = g + 4 * u;
         if (j < m) {
             const int c0 = lmc[j];
-            double pl[3];
+            double pl[LMD];
 #pragma unroll
-            for (int d = 0; d < 3; ++d) pl[d] = (double)plr[u][d] + ((c0 + d == c) ? fr.nz.q_lm : 0.0);
+            for (int d = 0; d < LMD; ++d) pl[d] = (double)plr[u][d] + ((c0 + d == c) ? fr.nz.q_lm : 0.0);
 #pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const int r = 3 * j + d;
-                const double* hr = hs + r * EKF_JCOLS;
+            for (int d = 0; d < RD; ++d) {
+                const int r = RD * j + d;
+                const double* hr = hs + r * JC;
                 double acc = 0.0;
 #pragma unroll
                 for (int a = 0; a < EKF_CAM; ++a) acc += hr[a] * pc[a];
 #pragma unroll
-                for (int e = 0; e < 3; ++e) acc += hr[10 + e] * pl[e];
+                for (int e = 0; e < LMD; ++e) acc += hr[10 + e] * pl[e];
                 fr.amat[(int64_t)r * fr.lda + c] = acc;
             }
         }
@@ -162,13 +164,18 @@ __global__ __launch_bounds__(256) void ekf_gather_kernel(EkfFrame fr) {
 
 template <typename T>
 void ekf_launch_gather(const EkfFrame& fr, hipStream_t s) {
-    const size_t lds = ((size_t)fr.k * EKF_JCOLS + 31 * 16) * sizeof(double) + (size_t)fr.m * sizeof(int) + 16;
     const int nb = fr.kpad / EKF_RB;
     const dim3 grid(fr.ncols / 64 + nb * (nb + 1) / 2);
+    if (fr.model == 1) {        // EKF_Rotations: 7 rows / detection, m <= 27
+        const size_t lds = ((size_t)fr.k * 20 + (EKF_CAM + 10 * 4) * 16) * sizeof(double) + (size_t)fr.m * sizeof(int) + 16;
+        hipLaunchKernelGGL((ekf_gather_kernel<T, 8, 1>), grid, dim3(256), lds, s, fr);
+        return;
+    }
+    const size_t lds = ((size_t)fr.k * EKF_JCOLS + 31 * 16) * sizeof(double) + (size_t)fr.m * sizeof(int) + 16;
     if (fr.m <= 32)
-        hipLaunchKernelGGL((ekf_gather_kernel<T, 8>), grid, dim3(256), lds, s, fr);
+        hipLaunchKernelGGL((ekf_gather_kernel<T, 8, 0>), grid, dim3(256), lds, s, fr);
     else
-        hipLaunchKernelGGL((ekf_gather_kernel<T, 16>), grid, dim3(256), lds, s, fr);
+        hipLaunchKernelGGL((ekf_gather_kernel<T, 16, 0>), grid, dim3(256), lds, s, fr);
 }
 template void ekf_launch_gather<float>(const EkfFrame&, hipStream_t);
 template void ekf_launch_gather<double>(const EkfFrame&, hipStream_t);
@@ -538,6 +545,10 @@ __global__ __launch_bounds__(64) void ekf_panel_mfma_kernel(EkfFrame fr) {
     part += __shfl_xor(part, 16);
     part += __shfl_xor(part, 32);                    // dx[col0 + j] in every lane group
     const int col = col0 + j;
+    if (fr.model == 1) {            // EKF_Rotations: every landmark has a quaternion -> separate kernel
+        if (g == 0 && col < fr.dims) fr.dxvec[col] = part;
+        return;
+    }
     double nv = 0.0;
     if (g == 0 && (col < 3 || (col >= EKF_CAM && col < fr.dims))) {
         nv = fr.state[col] + part;                   // extended_kalman_filter.py:134-135
@@ -622,6 +633,103 @@ template void ekf_launch_add_markers<float>(void*, int64_t, double*, int32_t, co
                                             const double*, double, int32_t, hipStream_t);
 template void ekf_launch_add_markers<double>(void*, int64_t, double*, int32_t, const double*,
                                              const double*, double, int32_t, hipStream_t);
+
+// EKF_Rotations state injection (ekf_with_rotations.py:142-177): xyz additive, quaternion
+// multiplicative (consistent scalar-first convention) for the camera and for EVERY landmark; the
+// landmarks' own error states are never written (they stay 0).  Thread 0 = camera.
+__global__ void ekf_inject_rot_kernel(EkfFrame fr, int n_lm) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n_lm) return;
+    const int c0 = (i == 0) ? 0 : EKF_CAM + 10 * (i - 1);
+    double* st = fr.state + c0;
+    const double* dx = fr.dxvec + c0;
+    double q[4] = {st[3], st[4], st[5], st[6]};
+    const double err[3] = {dx[7], dx[8], dx[9]};
+    ekf_quat_inject(q, err, 1);
+    const double x0 = st[0] + dx[0], x1 = st[1] + dx[1], x2 = st[2] + dx[2];
+    st[0] = x0; st[1] = x1; st[2] = x2;
+    for (int e = 0; e < 4; ++e) st[3 + e] = q[e];
+    if (i == 0) {
+        for (int e = 0; e < 3; ++e) st[7 + e] = 0.0;         // :157
+        if (fr.traj_row) {
+            fr.traj_row[0] = x0; fr.traj_row[1] = x1; fr.traj_row[2] = x2;
+            for (int e = 0; e < 4; ++e) fr.traj_row[3 + e] = q[e];
+        }
+    }
+}
+void ekf_launch_inject_rot(const EkfFrame& fr, int n_lm, hipStream_t s) {
+    hipLaunchKernelGGL(ekf_inject_rot_kernel, dim3((n_lm + 1 + 127) / 128), dim3(128), 0, s, fr, n_lm);
+}
+
+// EKF_Rotations.add_marker (ekf_with_rotations.py:275-335): pose = [tvec | rvec], rvec read as
+// extrinsic xyz Euler angles (:307-310); q_ml = from_matrix(R(q)^-1 R_cl) with SciPy's branch rule.
+template <typename T>
+__global__ void ekf_add_markers_rot_kernel(T* P, int64_t ld, double* state, int dims,
+                                           const double* pose6, const double* unc, double default_unc,
+                                           int count) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    double q[4] = {state[3], state[4], state[5], state[6]};
+    const double nq = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    const double a = q[0] * nq, u0 = q[1] * nq, u1 = q[2] * nq, u2 = q[3] * nq;
+    // rot_cm = R(q)^T
+    const double rcm[3][3] = {
+        {a * a + u0 * u0 - u1 * u1 - u2 * u2, 2 * (u0 * u1 + a * u2), 2 * (u0 * u2 - a * u1)},
+        {2 * (u0 * u1 - a * u2), a * a - u0 * u0 + u1 * u1 - u2 * u2, 2 * (u1 * u2 + a * u0)},
+        {2 * (u0 * u2 + a * u1), 2 * (u1 * u2 - a * u0), a * a - u0 * u0 - u1 * u1 + u2 * u2}};
+    const double* ps = pose6 + 6 * j;
+    const double ca = cos(ps[3]), sa = sin(ps[3]), cb = cos(ps[4]), sb = sin(ps[4]), cc = cos(ps[5]), sc = sin(ps[5]);
+    // R_cl = Rz(c) Ry(b) Rx(a)
+    const double rcl[3][3] = {{cc * cb, cc * sb * sa - sc * ca, cc * sb * ca + sc * sa},
+                              {sc * cb, sc * sb * sa + cc * ca, sc * sb * ca - cc * sa},
+                              {-sb, cb * sa, cb * ca}};
+    double mm[3][3];
+    for (int r = 0; r < 3; ++r)
+        for (int c2 = 0; c2 < 3; ++c2)
+            mm[r][c2] = rcm[r][0] * rcl[0][c2] + rcm[r][1] * rcl[1][c2] + rcm[r][2] * rcl[2][c2];
+    // matrix -> quaternion (x y z w), branch on the largest of (M00, M11, M22, trace)
+    const double tr = mm[0][0] + mm[1][1] + mm[2][2];
+    double dec[4] = {mm[0][0], mm[1][1], mm[2][2], tr};
+    int ch = 0;
+    for (int e = 1; e < 4; ++e)
+        if (dec[e] > dec[ch]) ch = e;
+    double qx[4];
+    if (ch != 3) {
+        const int i2 = ch, j2 = (ch + 1) % 3, k2 = (ch + 2) % 3;
+        qx[i2] = 1.0 - tr + 2.0 * mm[i2][i2];
+        qx[j2] = mm[j2][i2] + mm[i2][j2];
+        qx[k2] = mm[k2][i2] + mm[i2][k2];
+        qx[3] = mm[k2][j2] - mm[j2][k2];
+    } else {
+        qx[0] = mm[2][1] - mm[1][2];
+        qx[1] = mm[0][2] - mm[2][0];
+        qx[2] = mm[1][0] - mm[0][1];
+        qx[3] = 1.0 + tr;
+    }
+    const double nn = 1.0 / sqrt(qx[0] * qx[0] + qx[1] * qx[1] + qx[2] * qx[2] + qx[3] * qx[3]);
+    const int c0 = dims + 10 * j;
+    for (int d = 0; d < 3; ++d)
+        state[c0 + d] = rcm[d][0] * ps[0] + rcm[d][1] * ps[1] + rcm[d][2] * ps[2] + state[d];
+    state[c0 + 3] = qx[3] * nn;
+    state[c0 + 4] = qx[0] * nn;
+    state[c0 + 5] = qx[1] * nn;
+    state[c0 + 6] = qx[2] * nn;
+    for (int d = 7; d < 10; ++d) state[c0 + d] = 0.0;
+    for (int d = 0; d < 10; ++d) {
+        const double var = unc ? unc[10 * j + d] : default_unc;
+        P[(int64_t)(c0 + d) * ld + c0 + d] = (T)var;
+    }
+}
+template <typename T>
+void ekf_launch_add_markers_rot(void* cov, int64_t ld, double* state, int32_t dims, const double* pose6_dev,
+                                const double* unc_dev, double default_unc, int32_t count, hipStream_t s) {
+    hipLaunchKernelGGL(ekf_add_markers_rot_kernel<T>, dim3((count + 63) / 64), dim3(64), 0, s,
+                       static_cast<T*>(cov), ld, state, dims, pose6_dev, unc_dev, default_unc, count);
+}
+template void ekf_launch_add_markers_rot<float>(void*, int64_t, double*, int32_t, const double*,
+                                                const double*, double, int32_t, hipStream_t);
+template void ekf_launch_add_markers_rot<double>(void*, int64_t, double*, int32_t, const double*,
+                                                 const double*, double, int32_t, hipStream_t);
 
 template <typename T>
 __global__ void ekf_cov_diag_kernel(const T* P, int64_t ld, double* out, int count) {

@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = (
 class EkfConfig(C.Structure):
     _fields_ = [
         ("max_landmarks", C.c_int32), ("max_visible", C.c_int32), ("cov_dtype", C.c_int32),
-        ("quat_mode", C.c_int32), ("cov_kernel", C.c_int32), ("flags", C.c_int32),
+        ("quat_mode", C.c_int32), ("cov_kernel", C.c_int32), ("model", C.c_int32), ("reserved", C.c_int32), ("flags", C.c_int32),
         ("initial_camera_uncertainty", C.c_double), ("initial_landmark_uncertainty", C.c_double),
         ("r_uncertainty", C.c_double), ("q_cam", C.c_double), ("q_err", C.c_double),
         ("q_lm", C.c_double), ("stream", C.c_void_p),
@@ -110,7 +110,7 @@ class HipEkf:
 
     def __init__(self, max_landmarks: int, max_visible: int, cov_dtype="float64",
                  quat_mode="as_written", cov_kernel="auto", device="cuda:0", noise=None,
-                 lookahead=None):
+                 lookahead=None, model="ekf"):
         import torch
         self._torch = torch
         self.lib = load_library()
@@ -127,6 +127,8 @@ class HipEkf:
         kern = {"auto": EKF_COVK_AUTO, "valu": EKF_COVK_VALU, "mfma": EKF_COVK_MFMA}
         cfg.cov_kernel = kern[cov_kernel]
         cfg.flags = {None: 0, False: 1, True: 2}[lookahead]   # None = automatic
+        cfg.model = {"ekf": 0, "ekf_rotations": 1}[model]
+        self.lm_dims, self.rows_per_detection = (10, 7) if cfg.model == 1 else (3, 3)
         for key, val in (noise or {}).items():
             setattr(cfg, key, float(val))
         self.cov_dtype = str(cov_dtype)
@@ -173,7 +175,7 @@ class HipEkf:
 
     @property
     def dims(self) -> int:
-        return 3 * self.num_landmarks + 10
+        return self.lm_dims * self.num_landmarks + 10
 
     def reset(self, initial_pose):
         p = np.ascontiguousarray(initial_pose, dtype=np.float64)
@@ -181,17 +183,17 @@ class HipEkf:
         self._check(self.lib.ekf_reset(self.h, _dptr(p)))
 
     def add_markers(self, xyz, uncertainty=None):
-        xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 6 if self.lm_dims == 10 else 3)
         unc = None
         if uncertainty is not None:
             unc = np.ascontiguousarray(
-                np.broadcast_to(np.asarray(uncertainty, dtype=np.float64), xyz.shape))
+                np.broadcast_to(np.asarray(uncertainty, dtype=np.float64), (xyz.shape[0], self.lm_dims)))
         self._check(self.lib.ekf_add_markers(self.h, _dptr(xyz), _dptr(unc) if unc is not None else None,
                                              xyz.shape[0]))
 
     def observe(self, lm_index, z):
         idx = np.ascontiguousarray(lm_index, dtype=np.int32)
-        z = np.ascontiguousarray(z, dtype=np.float64).reshape(-1, 3)
+        z = np.ascontiguousarray(z, dtype=np.float64).reshape(-1, self.rows_per_detection)
         assert idx.shape[0] == z.shape[0]
         self._check(self.lib.ekf_observe(self.h, idx.ctypes.data_as(C.POINTER(C.c_int32)), _dptr(z),
                                          idx.shape[0]))
@@ -201,7 +203,7 @@ class HipEkf:
         detections); traj_t float64 [F,7] or None."""
         frames, m = idx_t.shape
         assert idx_t.is_cuda and z_t.is_cuda and idx_t.is_contiguous() and z_t.is_contiguous()
-        assert tuple(z_t.shape) == (frames, m, 3)
+        assert tuple(z_t.shape) == (frames, m, self.rows_per_detection)
         self._check(self.lib.ekf_observe_sequence_device(
             self.h, idx_t.data_ptr(), z_t.data_ptr(), m, frames,
             traj_t.data_ptr() if traj_t is not None else None))
@@ -228,7 +230,7 @@ class HipEkf:
 
     def set_state_cov(self, state, cov):
         state = np.ascontiguousarray(state, dtype=np.float64)
-        n_lm = (state.shape[0] - 10) // 3
+        n_lm = (state.shape[0] - 10) // self.lm_dims
         self._check(self.lib.ekf_set_state(self.h, _dptr(state), n_lm))
         cov = np.ascontiguousarray(cov, dtype=np.float64)
         assert cov.shape == (state.shape[0], state.shape[0])
@@ -252,8 +254,9 @@ class HipEkf:
         self._check(self.lib.ekf_debug_fetch(self.h, -1, _dptr(dummy), 1))
 
     def debug_fetch(self, what: str, m: int):
-        k, kp, n = 3 * m, -(-3 * m // 16) * 16, self.dims
-        shape = {"jac": (k, 13), "resid": (k,), "L": (kp, kp), "W": (kp, n), "A": (k, n),
+        rd = self.rows_per_detection
+        k, kp, n = rd * m, -(-rd * m // 16) * 16, self.dims
+        shape = {"jac": (k, 20 if rd == 7 else 13), "resid": (k,), "L": (kp, kp), "W": (kp, n), "A": (k, n),
                  "stamps": (64,)}[what]
         code = {"jac": 0, "resid": 1, "L": 2, "W": 3, "A": 4, "stamps": 5}[what]
         out = np.empty(shape)

@@ -20,6 +20,7 @@ from pathlib import Path
 import numpy as np
 
 from ..filters.base_filter import BaseFilter, cv2
+from ..filters.ekf_with_rotations import EKF_Rotations
 from ..filters.extended_kalman_filter import EKF
 from ..outputs.trajectory_writer import TrajectoryWriter
 
@@ -29,10 +30,12 @@ IMAGE_SIZE = 1920, 1080                             # run_slam.py:43
 
 
 def init_tracker(filter_type: str, initial_pose: np.ndarray, **kwargs) -> BaseFilter:
-    """run_slam.py:69-79.  Only the EKF back-end is accelerated here."""
+    """run_slam.py:69-79.  The two EKF back-ends are accelerated; the factor graph is GTSAM."""
     if filter_type == "ekf":
         return EKF(initial_pose, **kwargs)
-    if filter_type in ("ekf_rotations", "factorgraph"):
+    if filter_type == "ekf_rotations":
+        return EKF_Rotations(initial_pose, **kwargs)
+    if filter_type == "factorgraph":
         raise NotImplementedError(
             f"filter '{filter_type}' is outside this package's scope (SURVEY section 8)")
     raise ValueError(f"Unknown filter type: {filter_type}")

@@ -33,7 +33,7 @@ def camera_truth(frame: int):
 class SyntheticStream:
     """n landmarks, m visible per frame, seeded."""
 
-    def __init__(self, n: int, m: int, seed: int = 0, noise: float = 0.01):
+    def __init__(self, n: int, m: int, seed: int = 0, noise: float = 0.01, rvec_sigma: float = 0.0):
         if m > n:
             raise ValueError("m must be <= n")
         self.n, self.m, self.noise = n, m, noise
@@ -42,6 +42,7 @@ class SyntheticStream:
         lm[:, 0:2] = self.rng.uniform(-10.0, 10.0, size=(n, 2))
         lm[:, 2] = self.rng.uniform(5.0, 25.0, size=n)
         self.landmarks = lm
+        self.rvec_sigma = rvec_sigma     # > 0: poses[:, 3:6] carry noisy marker orientations (EKF_Rotations)
         self.frame = 0
 
     @property
@@ -54,6 +55,8 @@ class SyntheticStream:
         z = z + self.rng.normal(0.0, self.noise, size=z.shape)
         poses = np.zeros((len(ids), 6))
         poses[:, 0:3] = z
+        if self.rvec_sigma > 0.0:
+            poses[:, 3:6] = self.rng.normal(0.0, self.rvec_sigma, size=(len(ids), 3))
         self.frame += 1
         return np.asarray(ids, dtype=np.int32), poses
 

@@ -40,6 +40,10 @@ enum { EKF_COV_F64 = 0, EKF_COV_F32 = 1 };
  * SciPy's scalar-last from_quat); SCALAR_FIRST is the consistent convention
  * (what ekf_with_rotations.py:150-151 does). */
 enum { EKF_QUAT_AS_WRITTEN = 0, EKF_QUAT_SCALAR_FIRST = 1 };
+/* filter model: EKF = extended_kalman_filter.py (landmark xyz, 3 rows per detection);
+ * EKF_ROTATIONS = ekf_with_rotations.py (landmark [xyz | quat | err], 10 dims, 7 rows per
+ * detection [xyz_cl ; q_cl], consistent quaternion convention, q_cam default 0.2) */
+enum { EKF_MODEL_EKF = 0, EKF_MODEL_ROTATIONS = 1 };
 /* covariance-update kernel selection (0 = best available) */
 enum { EKF_COVK_AUTO = 0, EKF_COVK_VALU = 1, EKF_COVK_MFMA = 2 };
 
@@ -54,10 +58,12 @@ enum {
 
 typedef struct ekf_config {
     int32_t max_landmarks;  /* capacity n_max */
-    int32_t max_visible;    /* max observations per frame (<= 64) */
+    int32_t max_visible;    /* max observations per frame (<= 64; <= 27 for EKF_MODEL_ROTATIONS) */
     int32_t cov_dtype;      /* EKF_COV_F64 / EKF_COV_F32 */
     int32_t quat_mode;      /* EKF_QUAT_* */
     int32_t cov_kernel;     /* EKF_COVK_*: covariance-update kernel */
+    int32_t model;          /* EKF_MODEL_* */
+    int32_t reserved;
     int32_t flags;          /* cross-frame lookahead of ekf_observe_sequence_device: 0 = automatic
                              * (on when 3n+10 >= 6144, where the big update dominates), bit 0 = never,
                              * bit 1 = always */
@@ -94,6 +100,9 @@ int ekf_reset(ekf_filter *f, const double initial_camera_pose[10]);
  * t_ml = R(q)^-1 * cam_frame_xyz + cam_xyz with the CURRENT camera state,
  * appended to the state; P grows by diag(diag_uncertainty) (or 0.7 I if NULL).
  * Host pointers: cam_frame_xyz [count,3], diag_uncertainty [count,3] or NULL.
+ * EKF_MODEL_ROTATIONS (ekf_with_rotations.py:275-335): cam_frame_xyz is the full pose
+ * [count,6] = [tvec | rvec] (rvec read as extrinsic xyz Euler angles, :307-310), the new
+ * landmark is [t_ml | q_ml | 0 0 0], diag_uncertainty is [count,10].
  * The new landmarks get indices n .. n+count-1 (the marker-id -> index dict
  * stays on the Python side). */
 int ekf_add_markers(ekf_filter *f, const double *cam_frame_xyz,
@@ -101,7 +110,8 @@ int ekf_add_markers(ekf_filter *f, const double *cam_frame_xyz,
 
 /* EKF.predict + EKF.update for one frame (extended_kalman_filter.py:95-156):
  * lm_index [m] = landmark indices of the visible markers in `ids` order
- * (duplicates legal), z [m,3] = pose[0:3] of every detection.
+ * (duplicates legal), z [m,3] = pose[0:3] of every detection (EKF_MODEL_ROTATIONS: z [m,7] =
+ * [pose[0:3] | quaternion of from_euler("xyz", pose[3:6]), scalar first], :216-224).
  * ekf_observe takes host pointers (copied during the call);
  * ekf_observe_device takes device pointers that must stay valid until the
  * stream has consumed them. */

@@ -393,3 +393,125 @@ def test_c1_map_txt_matches_reference_at_the_horizon(tmp_path, golden_dir):
     assert gi == [k for k, _ in sorted(orc.landmarks.items(), key=lambda kv: kv[1])]
     assert rel_err(gx, orc.state[10:].reshape(-1, 3)) <= 1e-4
     assert rel_err(gu, orc.get_lm_uncertainties()) <= 1e-4
+
+
+# ---------------------------------------------------------------------------
+# EKF_Rotations (ekf_with_rotations.py) on the same kernels: 7 rows / detection, 10-dim landmarks
+# ---------------------------------------------------------------------------
+def _rot(**kw):
+    from aruco_slam_amd.filters.ekf_with_rotations import EKF_Rotations
+    return EKF_Rotations(INIT, **kw)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_g5_rotations_teacher_forced_vs_reference(dtype):
+    g = load_npz("g5_rotations.npz")
+    offs = g["offsets"]
+    for f in g["frames"]:
+        flt = _rot(max_landmarks=8, max_visible=6, cov_dtype=dtype)
+        _restore_hip(flt, g[f"f{f}_state0"], g[f"f{f}_P0"], g[f"f{f}_lm_ids"])
+        sl = slice(offs[f], offs[f + 1])
+        flt.observe(list(g["ids"][sl]), g["poses"][sl])
+        assert flt.state.shape == g[f"f{f}_state1"].shape
+        assert rel_err(flt.state, g[f"f{f}_state1"]) <= STEP_TOL[dtype], f
+        assert rel_err(flt.uncertainty, g[f"f{f}_P1"]) <= STEP_TOL[dtype], f
+
+
+def test_g5_rotations_intermediates():
+    from oracle.ekf_numpy import OracleEKFRotations
+    g = load_npz("g5_rotations.npz")
+    f, offs = 90, g["offsets"]
+    flt = _rot(max_landmarks=8, max_visible=6)
+    flt.backend.debug_enable_w()
+    _restore_hip(flt, g[f"f{f}_state0"], g[f"f{f}_P0"], g[f"f{f}_lm_ids"])
+    orc = OracleEKFRotations(INIT, mode="fast")
+    p0 = g[f"f{f}_P0"]
+    _restore_oracle(orc, g[f"f{f}_state0"], 0.5 * (p0 + p0.T), g[f"f{f}_lm_ids"])
+    sl = slice(offs[f], offs[f + 1])
+    ids, poses = list(g["ids"][sl]), g["poses"][sl]
+    z, hv, jac, col = orc.measurement_blocks(ids, poses)
+    flt.observe(ids, poses)
+    m = len(ids)
+    assert rel_err(flt.backend.debug_fetch("jac", m), jac.reshape(7 * m, 20)) <= 1e-13
+    assert rel_err(flt.backend.debug_fetch("resid", m), z - hv) <= 1e-13
+    dh = orc.dense_jacobian(jac, col)
+    pq = orc.uncertainty + np.diag(orc.process_noise_diag())
+    assert rel_err(flt.backend.debug_fetch("A", m), dh @ pq) <= 1e-13
+    s = dh @ pq @ dh.T + 0.9 * np.eye(7 * m)
+    chol = np.linalg.cholesky(0.5 * (s + s.T))
+    assert rel_err(flt.backend.debug_fetch("L", m)[:7 * m, :7 * m], chol) <= 1e-12
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-9), ("float32", 2e-5)])
+def test_g5_rotations_free_run_120_frames_vs_reference(dtype, tol):
+    g = load_npz("g5_rotations.npz")
+    offs = g["offsets"]
+    flt = _rot(max_landmarks=8, max_visible=6, cov_dtype=dtype)
+    cams = []
+    for f in range(len(g["has_detections"])):
+        sl = slice(offs[f], offs[f + 1])
+        ids = g["ids"][sl] if g["has_detections"][f] else None
+        _, cam, _, _ = flt.process_detections(ids, g["poses"][sl])
+        cams.append(np.asarray(cam[:7], dtype=np.float64).copy())
+    assert rel_err(np.stack(cams), g["cam"]) <= tol
+    assert rel_err(flt.state, g["final_state"]) <= tol
+    assert rel_err(flt.uncertainty, g["final_P"]) <= tol
+    assert rel_err(flt.get_lm_uncertainties(), np.diagonal(g["final_P"])[10:].reshape(-1, 10)) <= tol
+    assert list(flt.landmarks.keys()) == list(g["lm_ids"])
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_rotations_sequence_entry_matches_per_frame_calls(dtype):
+    """Model 1 through ekf_observe_sequence_device, with and without the cross-frame lookahead
+    (10 priority rows per next-frame landmark): bitwise the per-frame results."""
+    import torch
+    from aruco_slam_amd.filters.ekf_with_rotations import euler_xyz_to_quat
+    from aruco_slam_amd.synthetic import SyntheticStream
+    outs = []
+    for mode in ("per_frame", "sequence", "sequence_no_lookahead"):
+        s = SyntheticStream(40, 8, seed=4, rvec_sigma=0.05)
+        flt = _rot(max_landmarks=40, max_visible=8, cov_dtype=dtype,
+                   lookahead=(mode != "sequence_no_lookahead"))
+        for ids, poses in s.bootstrap():
+            flt.observe(ids, poses)
+        frames = [(ids.copy(), poses.copy()) for ids, poses in s.steady(7)]
+        frames[2][0][5] = frames[2][0][1]            # duplicate detection
+        frames[3][0][:] = frames[3][0][0]            # one landmark seen 8 times
+        if mode == "per_frame":
+            tr = []
+            for ids, poses in frames:
+                flt.observe(ids, poses)
+                tr.append(flt.state[:7].copy())
+            tr = np.stack(tr)
+        else:
+            idx = torch.tensor(np.stack([f[0] for f in frames]), dtype=torch.int32, device="cuda")
+            z = np.stack([np.hstack((f[1][:, :3], euler_xyz_to_quat(f[1][:, 3:6]))) for f in frames])
+            z = torch.tensor(z, dtype=torch.float64, device="cuda")
+            traj = torch.zeros((len(frames), 7), dtype=torch.float64, device="cuda")
+            flt.backend.observe_sequence(idx[:4], z[:4], traj[:4])
+            flt.backend.observe_sequence(idx[4:], z[4:], traj[4:])
+            flt.backend.sync()
+            tr = traj.cpu().numpy()
+        outs.append((tr, flt.state, flt.uncertainty))
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert np.array_equal(a, b)
+
+
+def test_rotations_vs_oracle_n100_fp32_and_fp64():
+    """Model 1 at a size the reference cannot reach in reasonable time (dims 1010, k = 112):
+    20 steady frames against the NumPy restatement (pinned by G5)."""
+    from oracle.ekf_numpy import OracleEKFRotations
+    from aruco_slam_amd.synthetic import SyntheticStream
+    for dtype, tol in (("float64", 1e-9), ("float32", 5e-5)):
+        s = SyntheticStream(100, 16, seed=9, rvec_sigma=0.05)
+        flt = _rot(max_landmarks=100, max_visible=16, cov_dtype=dtype)
+        orc = OracleEKFRotations(INIT, mode="fast")
+        frames = list(s.bootstrap()) + list(s.steady(20))
+        for ids, poses in frames:
+            flt.observe(ids, poses)
+            orc.observe(list(ids), poses)
+        assert rel_err(flt.state, orc.state) <= tol
+        assert rel_err(flt.uncertainty, orc.uncertainty) <= tol
+        p = flt.uncertainty
+        assert np.array_equal(p, p.T)

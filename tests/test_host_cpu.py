@@ -33,7 +33,7 @@ def test_config_struct_matches_header_and_defaults(lib):
     # extended_kalman_filter.py:21-27
     assert (cfg.initial_camera_uncertainty, cfg.initial_landmark_uncertainty) == (0.1, 0.7)
     assert (cfg.r_uncertainty, cfg.q_cam, cfg.q_err, cfg.q_lm) == (0.9, 0.3, 0.5, 0.01)
-    assert ctypes.sizeof(EkfConfig) == 6 * 4 + 6 * 8 + 8
+    assert ctypes.sizeof(EkfConfig) == 8 * 4 + 6 * 8 + 8
 
 
 @pytest.mark.parametrize("n,m,dtype,elem", [(1024, 32, 1, 4), (256, 16, 0, 8), (4096, 64, 1, 4)])
@@ -197,3 +197,16 @@ def test_run_slam_cli_contract():
         run_slam.init_tracker("factorgraph", np.zeros(10))
     frames = list(run_slam.detection_frames(str(REPO / "tests" / "golden" / "c1_detections.npz")))
     assert len(frames) == 200 and frames[0][1] is None and frames[1][1] is not None
+
+
+def test_euler_xyz_to_quat_matches_pinned_oracle():
+    """Host-side rvec -> quaternion of EKF_Rotations (ekf_with_rotations.py:216-219) against the
+    oracle's restatement, which G5 pins to SciPy through the reference."""
+    from aruco_slam_amd.filters.ekf_with_rotations import euler_xyz_to_quat
+    from oracle.ekf_numpy import quat_from_euler_xyz
+    rng = np.random.default_rng(3)
+    ang = rng.uniform(-np.pi, np.pi, size=(64, 3))
+    got = euler_xyz_to_quat(ang)
+    want = np.stack([quat_from_euler_xyz(a) for a in ang])
+    assert np.abs(got - want).max() <= 1e-15
+    assert np.abs(np.linalg.norm(got, axis=1) - 1.0).max() <= 1e-15
