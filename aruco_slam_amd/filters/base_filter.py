@@ -156,6 +156,28 @@ class BaseFilter:
             uncertainty = np.array(lines[i + 2].strip().split(", "), np.float64)
             self.add_marker(id_, pose, uncertainty)
 
+    # -- resume (no reference counterpart: its map restore is the dead :249-272) -----
+    def save_checkpoint(self, filename: str) -> None:
+        """Full filter state for an exact resume: state vector, dense covariance (float64 copy of
+        the device matrix) and the marker-id -> index table, as a plain ``.npz``."""
+        ids = [k for k, _ in sorted(self.get_lm_estimates(), key=lambda kv: kv[1])]
+        np.savez(filename, state=np.asarray(self.state, dtype=np.float64),
+                 cov=np.asarray(self.uncertainty, dtype=np.float64),
+                 marker_ids=np.asarray(ids, dtype=np.int64), filter=type(self).__name__)
+
+    def load_checkpoint(self, filename: str) -> None:
+        """Inverse of ``save_checkpoint`` on a filter of the same class; the device covariance
+        is overwritten bit-for-bit when the stored values fit the covariance dtype."""
+        with np.load(filename, allow_pickle=False) as ck:
+            if str(ck["filter"]) != type(self).__name__:
+                raise ValueError(f"checkpoint of {ck['filter']} loaded into {type(self).__name__}")
+            state, cov, ids = ck["state"], ck["cov"], ck["marker_ids"]
+        if len(ids) == 0:
+            return
+        self.backend.set_state_cov(state, cov)
+        self.landmarks = {int(k): i for i, k in enumerate(ids)}
+        self.num_landmarks = len(ids)
+
     # -- abstract back-end API, base_filter.py:327-381 ------------------------
     def observe(self, ids, poses) -> None:
         raise NotImplementedError(NOT_IMPLEMENTED_ERROR)

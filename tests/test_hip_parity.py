@@ -515,3 +515,27 @@ def test_rotations_vs_oracle_n100_fp32_and_fp64():
         assert rel_err(flt.uncertainty, orc.uncertainty) <= tol
         p = flt.uncertainty
         assert np.array_equal(p, p.T)
+
+
+@pytest.mark.parametrize("make,dtype", [(_ekf, "float64"), (_ekf, "float32"), (_rot, "float32")])
+def test_checkpoint_resume_is_bitwise(tmp_path, make, dtype):
+    """save_checkpoint / load_checkpoint: a filter restored mid-run continues
+    bitwise like the one that never stopped."""
+    from aruco_slam_amd.synthetic import SyntheticStream
+    s = SyntheticStream(24, 6, seed=5, rvec_sigma=0.05)
+    frames = list(s.bootstrap()) + list(s.steady(12))
+    a = make(max_landmarks=24, max_visible=6, cov_dtype=dtype)
+    for ids, poses in frames[:9]:
+        a.observe(ids, poses)
+    a.save_checkpoint(str(tmp_path / "ck.npz"))
+    b = make(max_landmarks=24, max_visible=6, cov_dtype=dtype)
+    b.load_checkpoint(str(tmp_path / "ck.npz"))
+    assert b.landmarks == a.landmarks and b.num_landmarks == a.num_landmarks
+    for ids, poses in frames[9:]:
+        a.observe(ids, poses)
+        b.observe(ids, poses)
+    assert np.array_equal(a.state, b.state)
+    assert np.array_equal(a.uncertainty, b.uncertainty)
+    with pytest.raises(ValueError):
+        other = _rot if make is _ekf else _ekf
+        other(max_landmarks=24, max_visible=6).load_checkpoint(str(tmp_path / "ck.npz"))
