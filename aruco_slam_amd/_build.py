@@ -10,8 +10,8 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB_DIR = PKG / "lib"
 LIB_PATH = LIB_DIR / "libekf_slam_hip.so"
-SOURCES = ["ekf_api.hip", "ekf_small_kernels.hip", "ekf_cov_update.hip"]
-HEADERS = ["ekf_device.h", "ekf_kernels.h", "../../include/ekf_slam_hip.h"]
+SOURCES = ["ekf_api.hip", "ekf_small_kernels.hip", "ekf_front.hip", "ekf_cov_update.hip"]
+HEADERS = ["ekf_device.h", "ekf_kernels.h", "ekf_solve_device.h", "../../include/ekf_slam_hip.h"]
 
 
 def hipcc() -> str:

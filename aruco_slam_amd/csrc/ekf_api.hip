@@ -42,7 +42,9 @@ struct Layout {
     int kmax;         // rd * max_visible rounded up to 16
     size_t elem;      // sizeof(cov element)
     size_t off_jac, off_resid, off_y, off_lmcol, off_amat, off_sblk, off_lmat, off_dinv, off_lop, off_dop, off_wpanel, off_wpanel2, off_prow, off_wdbg,
-        off_idx, off_z, off_status, off_stamps, off_dx, off_diag, off_xyz, off_unc, total;
+        off_idx, off_z, off_status, off_stamps, off_dx, off_diag, off_xyz, off_unc,
+        off_xs, off_xr, off_xl, off_done, total;
+    size_t xs_len, xl_len, xl_dop, xl_y;   // fused front kernel exchange buffers (doubles)
 };
 
 Layout make_layout(const ekf_config& c) {
@@ -79,6 +81,17 @@ Layout make_layout(const ekf_config& c) {
     L.off_diag = take((size_t)L.cap * 8);
     L.off_xyz = take((size_t)256 * 6 * 8);
     L.off_unc = take((size_t)256 * 10 * 8);
+    {
+        const size_t nb = (size_t)L.kmax / EKF_RB;
+        L.xs_len = nb * L.kmax * 16;
+        L.xl_dop = nb * (nb - 1) / 2 * 256 + 64;
+        L.xl_y = L.xl_dop + nb * 256;
+        L.xl_len = L.xl_y + L.kmax;
+        L.off_xs = take(L.xs_len * 8);
+        L.off_xr = take((size_t)L.kmax * 8);
+        L.off_xl = take(2 * L.xl_len * 8);
+        L.off_done = take(256);
+    }
     L.total = o;
     return L;
 }
@@ -117,6 +130,8 @@ struct ekf_filter {
     int n_lm = 0;
     int last_m = 0;
     bool debug_w = false;
+    uint64_t seq = 0;          // frames enqueued since reset (parity of the factor exchange buffer)
+    uint64_t done_total = 0;   // column chunks enqueued since reset (fused front kernel)
     // pinned staging ring for host-pointer observes
     char* pinned = nullptr;
     size_t slot_bytes = 0;
@@ -189,6 +204,18 @@ EkfFrame make_frame(ekf_filter* f, const int32_t* idx_dev, const double* z_dev, 
     fr.stamps = f->debug_w ? f->at<long long>(L.off_stamps) : nullptr;
     fr.nz = EkfNoise{f->cfg.q_cam, f->cfg.q_err, f->cfg.q_lm, f->cfg.r_uncertainty};
     fr.quat_mode = f->cfg.quat_mode;
+    fr.xs = f->at<double>(L.off_xs);
+    fr.xr = f->at<double>(L.off_xr);
+    fr.xl = f->at<double>(L.off_xl) + (f->seq & 1) * L.xl_len;
+    fr.xl_next = f->at<double>(L.off_xl) + ((f->seq + 1) & 1) * L.xl_len;
+    fr.xl_dop = (int32_t)L.xl_dop;
+    fr.xl_y = (int32_t)L.xl_y;
+    fr.xl_len = (int32_t)L.xl_len;
+    fr.n_lm = f->n_lm;
+    fr.done_ctr = f->at<unsigned long long>(L.off_done);
+    f->done_total += (uint64_t)(fr.ncols / 64);
+    fr.done_target = f->done_total;
+    f->seq++;
     return fr;
 }
 
@@ -209,12 +236,21 @@ int enqueue_frame(ekf_filter* f, const int32_t* idx_dev, const double* z_dev, in
     }
     hipEvent_t* ev_all = (ev && !f->timing_cov_only) ? ev : nullptr;
     if (ev_all) HIP_TRY(hipEventRecord(ev[0], f->stream));
-    if (f32) ekf_launch_gather<float>(fr, f->stream); else ekf_launch_gather<double>(fr, f->stream);
-    if (ev_all) HIP_TRY(hipEventRecord(ev[1], f->stream));
-    ekf_launch_solve(fr, f->stream);
-    if (ev_all) HIP_TRY(hipEventRecord(ev[2], f->stream));
-    if (f32) ekf_launch_panel<float>(fr, f->stream); else ekf_launch_panel<double>(fr, f->stream);
-    if (fr.model == 1) ekf_launch_inject_rot(fr, f->n_lm, f->stream);
+    if (!(f->cfg.flags & 4)) {
+        // one launch: timing slot 0 = the whole front kernel, slots 1 and 2 stay empty
+        if (f32) ekf_launch_front<float>(fr, f->stream); else ekf_launch_front<double>(fr, f->stream);
+        if (ev_all) {
+            HIP_TRY(hipEventRecord(ev[1], f->stream));
+            HIP_TRY(hipEventRecord(ev[2], f->stream));
+        }
+    } else {
+        if (f32) ekf_launch_gather<float>(fr, f->stream); else ekf_launch_gather<double>(fr, f->stream);
+        if (ev_all) HIP_TRY(hipEventRecord(ev[1], f->stream));
+        ekf_launch_solve(fr, f->stream);
+        if (ev_all) HIP_TRY(hipEventRecord(ev[2], f->stream));
+        if (f32) ekf_launch_panel<float>(fr, f->stream); else ekf_launch_panel<double>(fr, f->stream);
+        if (fr.model == 1) ekf_launch_inject_rot(fr, f->n_lm, f->stream);
+    }
     if (ev) HIP_TRY(hipEventRecord(ev[3], f->stream));
     if (f32) ekf_launch_cov_update<float>(fr, variant, f->stream);
     else ekf_launch_cov_update<double>(fr, variant, f->stream);
@@ -366,6 +402,15 @@ int ekf_reset(ekf_filter* f, const double initial_camera_pose[10]) {
     HIP_TRY(hipMemsetAsync(f->cov, 0, (size_t)L.cap * L.cap * L.elem, f->stream));
     HIP_TRY(hipMemsetAsync(f->state, 0, (size_t)L.cap * 8, f->stream));
     HIP_TRY(hipMemsetAsync(f->ws, 0, L.total, f->stream));
+    // arm the exchange buffers of the fused front kernel (ekf_solve_device.h: EKF_SENT_BITS)
+    HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(f->at<char>(L.off_xs)), (int)0xFFFBADC0u,
+                              L.xs_len * 2, f->stream));
+    HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(f->at<char>(L.off_xr)), (int)0xFFFBADC0u,
+                              (size_t)L.kmax * 2, f->stream));
+    HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(f->at<char>(L.off_xl)), (int)0xFFFBADC0u,
+                              L.xl_len * 4, f->stream));
+    f->seq = 0;
+    f->done_total = 0;
     HIP_TRY(hipMemcpyAsync(f->state, initial_camera_pose, 10 * sizeof(double), hipMemcpyHostToDevice,
                            f->stream));
     // P = 0.1 I_10  (extended_kalman_filter.py:48)
@@ -500,10 +545,14 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
                                  trajectory_dev ? trajectory_dev + (size_t)t * 7 : nullptr);
         fr.wpanel = wbuf[par];
         fr.prow = (t > 0) ? prow : nullptr;
-        if (f32) ekf_launch_gather<float>(fr, f->stream); else ekf_launch_gather<double>(fr, f->stream);
-        ekf_launch_solve(fr, f->stream);
-        if (f32) ekf_launch_panel<float>(fr, f->stream); else ekf_launch_panel<double>(fr, f->stream);
-        if (fr.model == 1) ekf_launch_inject_rot(fr, f->n_lm, f->stream);
+        if (!(f->cfg.flags & 4)) {
+            if (f32) ekf_launch_front<float>(fr, f->stream); else ekf_launch_front<double>(fr, f->stream);
+        } else {
+            if (f32) ekf_launch_gather<float>(fr, f->stream); else ekf_launch_gather<double>(fr, f->stream);
+            ekf_launch_solve(fr, f->stream);
+            if (f32) ekf_launch_panel<float>(fr, f->stream); else ekf_launch_panel<double>(fr, f->stream);
+            if (fr.model == 1) ekf_launch_inject_rot(fr, f->n_lm, f->stream);
+        }
         if (t + 1 < frames) {
             // the rows below are read from P_t: the big update of frame t-1 must be complete
             // (this also frees the W panel that frame t+1 will overwrite)

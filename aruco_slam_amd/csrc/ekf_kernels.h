@@ -52,8 +52,22 @@ struct EkfFrame {
     const void* prow;          // read by the gather kernel; null = read P
     EkfNoise nz;
     int32_t quat_mode;
+    // fused front kernel (ekf_front.hip): exchange buffers between its workgroups
+    double* xs;                // S blocks, layout of sblk; sentinel-armed, re-armed by the consumer
+    double* xr;                // [kmax] z - h (0 for rows k..kpad-1)
+    double* xl;                // this frame's factor exchange: [-L operands | Dinv operands | y]
+    double* xl_next;           // the other buffer, re-armed during this frame for the next one
+    int32_t xl_dop, xl_y;      // offsets (doubles) of the Dinv operands and of y inside xl
+    int32_t xl_len;            // doubles per buffer
+    int32_t n_lm;              // landmarks in the state (model 1 injection)
+    unsigned long long* done_ctr;      // chunks finished since reset (device)
+    unsigned long long done_target;    // value of done_ctr once this frame's last chunk is done
 };
 
+// fused gather + solve + panel (+ injection); see ekf_front.hip
+template <typename T> void ekf_launch_front(const EkfFrame& fr, hipStream_t s);
+int ekf_solve_stream_ring(int kpad, int k);
+int ekf_solve_stream_lds_bytes(int kpad, int k);
 template <typename T> void ekf_launch_gather(const EkfFrame& fr, hipStream_t s);
 void ekf_launch_solve(const EkfFrame& fr, hipStream_t s);
 template <typename T> void ekf_launch_panel(const EkfFrame& fr, hipStream_t s);

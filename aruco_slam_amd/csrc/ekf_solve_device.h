@@ -1,0 +1,156 @@
+// Device helpers of the blocked Cholesky shared by the stand-alone solve kernel
+// (ekf_small_kernels.hip) and the fused front kernel (ekf_front.hip).  gfx950 only.
+#pragma once
+#include "ekf_kernels.h"
+
+// Cross-workgroup exchange inside ONE launch (fused front kernel): data goes through agent-scope
+// relaxed atomics (global_load/store ... sc1: coherent across the 8 XCD L2s without any cache
+// flush) and readiness is carried by the data itself: an exchange buffer holds EKF_SENT (a NaN
+// payload no computation produces) until the producer overwrites it.
+#define EKF_SENT_BITS 0xFFFBADC0FFFBADC0ull
+#define EKF_SENT_WORD 0xFFFBADC0u
+#define EKF_SPIN_MAX 400000
+__device__ __forceinline__ double ekf_sent() { return __longlong_as_double((long long)EKF_SENT_BITS); }
+__device__ __forceinline__ bool ekf_is_sent(double v) { return __double_as_longlong(v) == (long long)EKF_SENT_BITS; }
+__device__ __forceinline__ double ekf_ldc(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ekf_stc(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool COH> __device__ __forceinline__ double ekf_ldx(const double* p) { return COH ? ekf_ldc(p) : *p; }
+
+typedef double sf64x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double ekf_readlane_f64(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double ekf_rsqrt_f64(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double e = __builtin_fma(-h * y, y, 0.5);
+        y = __builtin_fma(y, e, y);
+    }
+    return y;
+}
+
+// --------------------------------------------------------------------------
+// solve, column-streaming blocked Cholesky (kpad <= 192).  16 waves, one workgroup.
+//   * only 4 block columns of S live in LDS (ring); a finished block column b is emitted from
+//     the pivot waves' registers in MFMA-operand order (-L, `lop`) -- the layout the panel kernel
+//     reads anyway -- and is read back from there by the later left-looking updates;
+//   * per block column b:   (A) all waves : column b -= L[:, b-1] L[b, b-1]^T        (LDS operands)
+//                           (B) pivot waves: 16-pivot chain (lane = row, v_readlane broadcast),
+//                               one more wave carries the diagonal rows + I_16 -> Dinv_b;
+//                               every other wave meanwhile: column b+1 -= (q = b-1 term) and
+//                               column b+2 (fetched from `sblk` if it is not resident yet) gets
+//                               its q <= b-1 terms (LDS while column q is resident, else `lop`);
+//     so all but one update term per column hide behind the pivot chain.
+//   * S itself comes finished from the gather launch (`sblk`).
+//   * the residual rides along as row kp (its factor row is y = L^-1 (z - h)).
+// --------------------------------------------------------------------------
+#define SV_T 512
+#define SV_CLD 18
+
+__device__ __forceinline__ size_t sv_lop_index(int i, int q) { return (size_t)(i * (i - 1) / 2 + q) * 256; }
+
+// C-in / C-out of row block i of the column buffer `tgt` (block column tc), one wave
+struct SvAcc { sf64x4 t, t2; };
+__device__ __forceinline__ void sv_acc_load(SvAcc& a, const double* tgt, int kp, int i, int c, int g) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        a.t[r] = tgt[min(EKF_RB * i + g + 4 * r, kp) * SV_CLD + c];
+        a.t2[r] = 0.0;
+    }
+}
+__device__ __forceinline__ void sv_acc_store(const SvAcc& a, double* tgt, int kp, int i, int c, int g) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = EKF_RB * i + g + 4 * r;
+        if (row <= kp) tgt[row * SV_CLD + c] = a.t[r] + a.t2[r];
+    }
+}
+// one q term, operands from the LDS buffer of block column q:  -= L_iq L_tq^T
+__device__ __forceinline__ void sv_term_lds(SvAcc& a, const double* qbuf, int kp, int i, int tc, int c, int g,
+                                            bool second = false) {
+    const double* ar = qbuf + (size_t)min(EKF_RB * i + c, kp) * SV_CLD + g;   // residual block: rows alias kp
+    const double* br = qbuf + (size_t)(EKF_RB * tc + c) * SV_CLD + g;
+    double av[4], bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { av[r] = ar[4 * r]; bv[r] = br[4 * r]; }
+    if (second) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a.t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[r], bv[r], a.t2, 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a.t = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[r], bv[r], a.t, 0, 0, 0);
+    }
+}
+// q in [0, q1), operands from global: lop (-L blocks) and, for the residual block, y
+template <bool COH = false>
+__device__ __forceinline__ void sv_terms_glb(SvAcc& a, const double* __restrict__ lop,
+                                             const double* __restrict__ yv, int nb, int i, int tc, int q1,
+                                             int g, int lane) {
+    if (q1 <= 0) return;
+    // operands of term q+1 are in flight while the MFMAs of term q run
+    double av[4], bv[4], an[4], bn[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        av[r] = (i < nb) ? ekf_ldx<COH>(lop + sv_lop_index(i, 0) + r * 64 + lane) : -ekf_ldx<COH>(yv + g + 4 * r);
+        bv[r] = -ekf_ldx<COH>(lop + sv_lop_index(tc, 0) + r * 64 + lane);
+    }
+    for (int q = 0; q < q1; ++q) {
+        const int qn = min(q + 1, q1 - 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            an[r] = (i < nb) ? ekf_ldx<COH>(lop + sv_lop_index(i, qn) + r * 64 + lane)
+                             : -ekf_ldx<COH>(yv + EKF_RB * qn + g + 4 * r);
+            bn[r] = -ekf_ldx<COH>(lop + sv_lop_index(tc, qn) + r * 64 + lane);
+        }
+        if (q & 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a.t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[r], bv[r], a.t2, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a.t = __builtin_amdgcn_mfma_f64_16x16x4f64(av[r], bv[r], a.t, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { av[r] = an[r]; bv[r] = bn[r]; }
+    }
+}
+
+// S entries of row block i of block column tc (rows 16i.., columns 16tc..): one wave, lane =
+// (row rr = lane & 15, column group cg = lane >> 4 -> 4 columns)
+// One 16x16 block (row block i, block column tc) of S as the gather launch left it in `sblk`
+// ([block column][row][16], 2 KB contiguous per block): lane = (row rr = lane >> 2, 4 columns).
+// Row block nb is the residual row: z - h of the block column's 16 rows.
+__device__ __forceinline__ sf64x4 sv_fetch_block(const EkfFrame& fr, int kp, int nb, int i, int tc, int lane) {
+    const int rr = lane >> 2, cg = lane & 3;
+    sf64x4 v;
+    if (i < nb) {
+        const double* src = fr.sblk + ((size_t)tc * fr.sblk_rows + EKF_RB * i + rr) * 16 + 4 * cg;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) v[x] = src[x];
+    } else {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const int r2 = EKF_RB * tc + 4 * cg + x;
+            const double rv = fr.resid[min(r2, fr.k - 1)];
+            v[x] = (r2 < fr.k) ? rv : 0.0;
+        }
+    }
+    return v;
+}
+__device__ __forceinline__ void sv_put_block(const sf64x4& v, double* tgt, int kp, int nb, int i, int lane) {
+    const int rr = lane >> 2, cg = lane & 3;
+    if (i == nb && rr != 0) return;
+    const int row = (i < nb) ? EKF_RB * i + rr : kp;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) tgt[row * SV_CLD + 4 * cg + x] = v[x];
+}
+

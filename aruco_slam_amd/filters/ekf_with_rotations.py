@@ -45,7 +45,7 @@ class EKF_Rotations(BaseFilter):  # noqa: N801  (name of the reference class)
 
     def __init__(self, initial_camera_pose, *, max_landmarks: int = 50, max_visible: int | None = None,
                  cov_dtype: str = "float64", cov_kernel: str = "auto", device: str = "cuda:0",
-                 lookahead: bool | None = None) -> None:
+                 lookahead: bool | None = None, fused: bool = True) -> None:
         super().__init__(initial_camera_pose, None)
         self._initial_pose = np.array(initial_camera_pose)
         if self._initial_pose.shape != (CAM_DIMS,):
@@ -55,7 +55,7 @@ class EKF_Rotations(BaseFilter):  # noqa: N801  (name of the reference class)
         if max_visible is None:
             max_visible = min(max_landmarks, 27)     # 7 rows per detection, k <= 192
         self._hip = HipEkf(max_landmarks, max_visible, cov_dtype=cov_dtype, quat_mode="scalar_first",
-                           cov_kernel=cov_kernel, device=device, lookahead=lookahead,
+                           cov_kernel=cov_kernel, device=device, lookahead=lookahead, fused=fused,
                            model="ekf_rotations",
                            noise={"initial_camera_uncertainty": INITIAL_CAMERA_UNCERTAINTY,
                                   "initial_landmark_uncertainty": INITIAL_LANDMARK_UNCERTAINTY,

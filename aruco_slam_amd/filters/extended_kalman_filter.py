@@ -35,7 +35,8 @@ class EKF(BaseFilter):
     def __init__(self, initial_camera_pose, aruco_dict=None, *, max_landmarks: int = 50,
                  max_visible: int | None = None, cov_dtype: str = "float64",
                  quat_update: str = "as_written", cov_kernel: str = "auto",
-                 device: str = "cuda:0", map_file=None, lookahead: bool | None = None) -> None:
+                 device: str = "cuda:0", map_file=None, lookahead: bool | None = None,
+                 fused: bool = True) -> None:
         """Positional arguments as the reference (:40-43).  Keyword-only extras:
         capacity (DICT_5X5_50 has 50 ids, base_filter.py:81-82), covariance
         storage dtype, and the quaternion-injection convention
@@ -50,7 +51,7 @@ class EKF(BaseFilter):
         if max_visible is None:
             max_visible = min(max_landmarks, 64)
         self._hip = HipEkf(max_landmarks, max_visible, cov_dtype=cov_dtype,
-                           quat_mode=quat_update, cov_kernel=cov_kernel, device=device, lookahead=lookahead,
+                           quat_mode=quat_update, cov_kernel=cov_kernel, device=device, lookahead=lookahead, fused=fused,
                            noise={"initial_camera_uncertainty": INITIAL_CAMERA_UNCERTAINTY,
                                   "initial_landmark_uncertainty": INITIAL_LANDMARK_UNCERTAINTY,
                                   "r_uncertainty": R_UNCERTAINTY, "q_cam": Q_UNCERTAINTY_CAM,

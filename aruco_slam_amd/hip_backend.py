@@ -110,7 +110,7 @@ class HipEkf:
 
     def __init__(self, max_landmarks: int, max_visible: int, cov_dtype="float64",
                  quat_mode="as_written", cov_kernel="auto", device="cuda:0", noise=None,
-                 lookahead=None, model="ekf"):
+                 lookahead=None, model="ekf", fused=True):
         import torch
         self._torch = torch
         self.lib = load_library()
@@ -127,6 +127,8 @@ class HipEkf:
         kern = {"auto": EKF_COVK_AUTO, "valu": EKF_COVK_VALU, "mfma": EKF_COVK_MFMA}
         cfg.cov_kernel = kern[cov_kernel]
         cfg.flags = {None: 0, False: 1, True: 2}[lookahead]   # None = automatic
+        if not fused:
+            cfg.flags |= 4        # separate gather / solve / panel launches
         cfg.model = {"ekf": 0, "ekf_rotations": 1}[model]
         self.lm_dims, self.rows_per_detection = (10, 7) if cfg.model == 1 else (3, 3)
         for key, val in (noise or {}).items():

@@ -66,7 +66,8 @@ typedef struct ekf_config {
     int32_t reserved;
     int32_t flags;          /* cross-frame lookahead of ekf_observe_sequence_device: 0 = automatic
                              * (on when 3n+10 >= 6144, where the big update dominates), bit 0 = never,
-                             * bit 1 = always */
+                             * bit 1 = always.  bit 2: run gather / solve / panel as three separate
+                             * launches instead of the fused front kernel (same results, bit for bit) */
     /* noise constants, defaults = extended_kalman_filter.py:21-27 */
     double initial_camera_uncertainty;   /* 0.1  */
     double initial_landmark_uncertainty; /* 0.7  */

@@ -539,3 +539,43 @@ def test_checkpoint_resume_is_bitwise(tmp_path, make, dtype):
     with pytest.raises(ValueError):
         other = _rot if make is _ekf else _ekf
         other(max_landmarks=24, max_visible=6).load_checkpoint(str(tmp_path / "ck.npz"))
+
+
+# ---------------------------------------------------------------------------
+# fused front kernel (ekf_front.hip) vs the three separate launches (cfg.flags bit 2)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("make,n,m,dtype", [(_ekf, 24, 8, "float64"), (_ekf, 24, 8, "float32"),
+                                            (_ekf, 256, 16, "float64"), (_ekf, 1024, 32, "float32"),
+                                            (_ekf, 128, 64, "float32"),      # k = 192: LDS ring in the factor
+                                            (_rot, 20, 6, "float64"), (_rot, 40, 27, "float32")])
+def test_fused_front_kernel_is_bitwise_the_separate_launches(make, n, m, dtype):
+    from aruco_slam_amd.synthetic import SyntheticStream
+    outs = []
+    for fused in (True, False):
+        s = SyntheticStream(n, m, seed=1, rvec_sigma=0.05)
+        flt = make(max_landmarks=n, max_visible=m, cov_dtype=dtype, fused=fused)
+        for ids, poses in list(s.bootstrap()) + list(s.steady(5)):
+            flt.observe(ids, poses)
+        flt.observe(ids[:max(1, m // 3)], poses[:max(1, m // 3)])      # smaller k after a larger one
+        flt.observe(ids, poses)
+        outs.append((flt.state, flt.uncertainty))
+    assert np.isfinite(outs[0][0]).all()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("make,n,m,tol", [(_ekf, 128, 64, 1e-9), (_rot, 40, 27, 1e-9)])
+def test_k192_vs_oracle(make, n, m, tol):
+    """Largest supported innovation (k = 192 / 189, factor streamed through the LDS ring)."""
+    from oracle.ekf_numpy import OracleEKF, OracleEKFRotations
+    from aruco_slam_amd.synthetic import SyntheticStream
+    s = SyntheticStream(n, m, seed=3, rvec_sigma=0.05)
+    flt = make(max_landmarks=n, max_visible=m) if make is _rot else make(max_landmarks=n, max_visible=m,
+                                                                        quat_update="scalar_first")
+    orc = OracleEKFRotations(INIT, mode="fast") if make is _rot else OracleEKF(INIT, mode="fast",
+                                                                             quat_mode="scalar_first")
+    for ids, poses in list(s.bootstrap()) + list(s.steady(6)):
+        flt.observe(ids, poses)
+        orc.observe(list(ids), poses)
+    assert rel_err(flt.state, orc.state) <= tol
+    assert rel_err(flt.uncertainty, orc.uncertainty) <= tol
