@@ -33,8 +33,11 @@ __device__ __forceinline__ double ekf_qdiag(int i, int dims, const EkfNoise& nz)
 }
 
 // h (3) and dh (3 x 13) for one landmark.  cam = state[0:10], lm = state[c0:c0+3].
+// No fused-multiply-add contraction in the measurement model: it is evaluated by several kernels /
+// workgroup roles, and every instance has to produce the same bits whatever it is inlined into.
 __device__ inline void ekf_measure(const double* __restrict__ cam, const double* __restrict__ lm,
                                    double h[3], double J[3][EKF_JCOLS]) {
+#pragma clang fp contract(off)
     const double a = cam[3];
     const double u[3] = {cam[4], cam[5], cam[6]};
     const double v[3] = {lm[0] - cam[0], lm[1] - cam[1], lm[2] - cam[2]};
@@ -104,6 +107,7 @@ __device__ inline void ekf_quat_inject(double q[4], const double err[3], int mod
 // sympy's Quaternion.inverse() is conj / |q|^2.
 __device__ inline void ekf_measure_rot(const double* __restrict__ cam, const double* __restrict__ lm,
                                        double h[7], double J[7][20]) {
+#pragma clang fp contract(off)
     double h3[3], j13[3][EKF_JCOLS];
     ekf_measure(cam, lm, h3, j13);
     for (int i = 0; i < 3; ++i) {

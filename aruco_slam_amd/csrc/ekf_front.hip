@@ -4,10 +4,11 @@
 //
 // Workgroup roles by blockIdx.x (a workgroup only ever waits for LOWER-indexed workgroups, which
 // the dispatcher starts first, so the waits cannot deadlock whatever the residency):
-//   [0, nS)        one 16x16 block of S each, straight from P (nS = nb (nb+1) / 2)
-//   nS             the factorisation: streams the S blocks into LDS as they appear, runs the
+//   0              measurement model: Jacobian rows / residual for the other roles
+//   [1, nS]        one 16x16 block of S each, straight from P (nS = nb (nb+1) / 2)
+//   nS + 1         the factorisation: streams the S blocks into LDS as they appear, runs the
 //                  pivot chain, publishes -L / Dinv / y block column by block column
-//   (nS, nS+nch]   one chunk of 64 columns each: A chunk into LDS, then the right-looking blocked
+//   > nS + 1       one chunk of 64 columns each: A chunk into LDS, then the right-looking blocked
 //                  forward substitution in registers, consuming block column q of the factor as soon
 //                  as it is published; W chunk, dx chunk; the LAST chunk to finish injects dx into
 //                  the state (every reader of the old state has passed by then)
@@ -26,6 +27,12 @@
 typedef double pf64x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void ekf_poll_sleep() { __builtin_amdgcn_s_sleep(4); }
+// cacheable load (may hit in L1 / this XCD's L2) that the compiler neither hoists nor merges; used
+// for the first attempt once a poller has seen the producer's data, retries go through ekf_ldc
+__device__ __forceinline__ double ekf_ldw(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+__device__ __forceinline__ double ekf_ldt(const double* p, bool coherent) { return coherent ? ekf_ldc(p) : ekf_ldw(p); }
 
 // ---------------------------------------------------------------------------------------------
 // measurement model of every detection into LDS (one thread per detection), shared by the S-block
@@ -33,7 +40,7 @@ __device__ __forceinline__ void ekf_poll_sleep() { __builtin_amdgcn_s_sleep(4); 
 // ---------------------------------------------------------------------------------------------
 template <int MODEL>
 __device__ __forceinline__ void fr_measure(const EkfFrame& fr, const double* cam, const int* lmc, double* hs,
-                                           int tid, bool publish) {
+                                           double* rsd, int tid, bool publish) {
     constexpr int RD = EkfModel<MODEL>::RD, LMD = EkfModel<MODEL>::LMD, JC = EkfModel<MODEL>::JC;
     if (tid < fr.m) {
         const int c0 = lmc[tid];
@@ -47,13 +54,13 @@ __device__ __forceinline__ void fr_measure(const EkfFrame& fr, const double* cam
                 for (int a = 0; a < JC; ++a) fr.jac[(size_t)(RD * tid + d) * EKF_JLD + a] = J[d][a];
                 const double rv = fr.z[RD * tid + d] - h[d];          // additive residual (:140)
                 fr.resid[RD * tid + d] = rv;
-                ekf_stc(fr.xr + RD * tid + d, rv);
+                rsd[RD * tid + d] = rv;
             }
             fr.lmcol[tid] = c0;
         }
     }
     if (publish)
-        for (int r = fr.k + tid; r < fr.kpad; r += FR_T) ekf_stc(fr.xr + r, 0.0);
+        for (int r = fr.k + tid; r < fr.kpad; r += FR_T) rsd[r] = 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -66,6 +73,7 @@ __device__ __forceinline__ void fr_role_sblock(const EkfFrame& fr, int sb, int n
     double* hs = sm;                                    // [k][JC]
     double* us = sm + fr.k * JC;                        // [NSLOT][16]
     int* lmc = reinterpret_cast<int*>(us + NSLOT * 16);
+    double* rsd = us + NSLOT * 16 + 32;                 // [kpad] z - h (workgroup 0 only)
     const int tid = threadIdx.x, m = fr.m, k = fr.k;
     const T* __restrict__ P = static_cast<const T*>(fr.cov);
     const T* __restrict__ prow = static_cast<const T*>(fr.prow);
@@ -73,36 +81,56 @@ __device__ __forceinline__ void fr_role_sblock(const EkfFrame& fr, int sb, int n
     double cam[EKF_CAM];
 #pragma unroll
     for (int a = 0; a < EKF_CAM; ++a) cam[a] = fr.state[a];
+    if (fr.stamps && sb == 0 && tid == 0) fr.stamps[60] = wall_clock64();
     if (tid < m) lmc[tid] = EKF_CAM + LMD * fr.idx[tid];
     __syncthreads();
-    fr_measure<MODEL>(fr, cam, lmc, hs, tid, sb == 0);
-    __syncthreads();
+    // this thread's entry of U (slot, c2): its P values are requested before the measurement model
+    // is evaluated, so the two dependent memory round trips overlap
     int bi = 0, bj = sb;
     while (bj > bi) { bj -= bi + 1; ++bi; }
     const int j0 = (16 * bi) / RD;
-    for (int e = tid; e < NSLOT * 16; e += FR_T) {
-        const int slot = e >> 4, c2 = e & 15, r2 = 16 * bj + c2;
-        const int j = j0 + (slot - EKF_CAM) / LMD, d = (slot - EKF_CAM) % LMD;
-        double acc = 0.0;
-        if (r2 < k && (slot < EKF_CAM || j < m)) {
-            const int rho = (slot < EKF_CAM) ? slot : lmc[j] + d;
-            const T* prw = prow ? prow + (int64_t)((slot < EKF_CAM) ? slot : EKF_CAM + LMD * j + d) * fr.ldw
-                                : P + (int64_t)rho * ld;
-            const double* h2 = hs + r2 * JC;
-            const int c20 = lmc[r2 / RD];
-            T pv[JC];
+    constexpr int NE = (NSLOT * 16 + FR_T - 1) / FR_T;  // entries of U per thread (1 or 2)
+    int urho[NE], uc20[NE], ur2[NE];
+    bool uact[NE];
+    T pv[NE][JC];
 #pragma unroll
-            for (int b = 0; b < EKF_CAM; ++b) pv[b] = prw[b];
+    for (int n = 0; n < NE; ++n) {
+        const int ue = tid + FR_T * n;
+        const int uslot = ue >> 4, uc2 = ue & 15;
+        ur2[n] = 16 * bj + uc2;
+        const int uj = j0 + (uslot - EKF_CAM) / LMD, ud = (uslot - EKF_CAM) % LMD;
+        uact[n] = ue < NSLOT * 16 && ur2[n] < k && (uslot < EKF_CAM || uj < m);
+        urho[n] = 0;
+        uc20[n] = 0;
+        if (uact[n]) {
+            urho[n] = (uslot < EKF_CAM) ? uslot : lmc[uj] + ud;
+            const T* prw = prow ? prow + (int64_t)((uslot < EKF_CAM) ? uslot : EKF_CAM + LMD * uj + ud) * fr.ldw
+                                : P + (int64_t)urho[n] * ld;
+            uc20[n] = lmc[ur2[n] / RD];
 #pragma unroll
-            for (int b = 0; b < LMD; ++b) pv[EKF_CAM + b] = prw[c20 + b];
+            for (int b = 0; b < EKF_CAM; ++b) pv[n][b] = prw[b];
 #pragma unroll
-            for (int b = 0; b < JC; ++b) {
-                const int col = (b < EKF_CAM) ? b : c20 + (b - EKF_CAM);
-                const double pq = (double)pv[b] + ((col == rho) ? ekf_qdiag(rho, fr.dims, fr.nz) : 0.0);
-                acc += pq * h2[b];
-            }
+            for (int b = 0; b < LMD; ++b) pv[n][EKF_CAM + b] = prw[uc20[n] + b];
         }
-        us[e] = acc;
+    }
+    fr_measure<MODEL>(fr, cam, lmc, hs, rsd, tid, false);
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NE; ++n) {
+        const int ue = tid + FR_T * n;
+        if (ue < NSLOT * 16) {
+            double acc = 0.0;
+            if (uact[n]) {
+                const double* h2 = hs + ur2[n] * JC;
+#pragma unroll
+                for (int b = 0; b < JC; ++b) {
+                    const int col = (b < EKF_CAM) ? b : uc20[n] + (b - EKF_CAM);
+                    const double pq = (double)pv[n][b] + ((col == urho[n]) ? ekf_qdiag(urho[n], fr.dims, fr.nz) : 0.0);
+                    acc += pq * h2[b];
+                }
+            }
+            us[ue] = acc;
+        }
     }
     __syncthreads();
     if (tid < 256) {
@@ -124,6 +152,8 @@ __device__ __forceinline__ void fr_role_sblock(const EkfFrame& fr, int sb, int n
         }
         ekf_stc(fr.xs + ((size_t)bj * fr.sblk_rows + r1) * 16 + c2, v);
     }
+    if (fr.stamps && sb == nS - 1 && tid == 0) fr.stamps[61] = wall_clock64();
+
     // re-arm the factor exchange buffer of the NEXT frame (the one frame t-1 used)
     {
         const int64_t lo = (int64_t)fr.xl_len * sb / nS, hi = (int64_t)fr.xl_len * (sb + 1) / nS;
@@ -133,51 +163,141 @@ __device__ __forceinline__ void fr_role_sblock(const EkfFrame& fr, int sb, int n
 }
 
 // ---------------------------------------------------------------------------------------------
+// role: measurement model for the other roles (workgroup 0): Jacobian rows for the chunks, residual
+// for the factorisation, plus the copies that ekf_debug_fetch reads.  Its own workgroup, so that no
+// S block is delayed by the publication.
+// ---------------------------------------------------------------------------------------------
+template <int MODEL>
+__device__ __forceinline__ void fr_role_measure(const EkfFrame& fr, double* sm) {
+    constexpr int LMD = EkfModel<MODEL>::LMD, JC = EkfModel<MODEL>::JC;
+    double* hs = sm;                                    // [k][JC]
+    double* rsd = sm + fr.k * JC;                       // [kpad]
+    int* lmc = reinterpret_cast<int*>(rsd + fr.kpad);
+    const int tid = threadIdx.x;
+    double cam[EKF_CAM];
+#pragma unroll
+    for (int a = 0; a < EKF_CAM; ++a) cam[a] = fr.state[a];
+    if (tid < fr.m) lmc[tid] = EKF_CAM + LMD * fr.idx[tid];
+    __syncthreads();
+    fr_measure<MODEL>(fr, cam, lmc, hs, rsd, tid, true);
+    __syncthreads();
+    // whole cache lines per store instruction (a line that is polled must not be written piecemeal)
+    double* __restrict__ xj = fr.xl + fr.xl_jac;
+    const int nel = fr.k * JC;
+    for (int e = tid; e < nel; e += FR_T) ekf_stc(xj + e, hs[e]);
+    for (int e = tid; e < fr.kpad; e += FR_T) ekf_stc(fr.xr + e, rsd[e]);
+    if (fr.stamps && tid == 0) fr.stamps[55] = wall_clock64();
+}
+
+// ---------------------------------------------------------------------------------------------
 // role: factorisation (the stand-alone solve kernel with exchange-buffer input / output)
 // ---------------------------------------------------------------------------------------------
-struct FrBlockSrc { double* p; bool live; };
+// One 16x16 block of S (row block i of block column tc; i == nb: the residual row) travels from the
+// exchange buffer into the factor's LDS column buffer.  Lane <-> word mapping: word x*64 + lane of the
+// 2 KB block, i.e. row 4x + (lane >> 4), column lane & 15: every load / re-arm store instruction
+// covers 512 contiguous bytes.  Polling touches ONE word (the block's last); the bulk goes through
+// cacheable loads (sc1 stores are written through, see tools/xcd_exchange_probe.hip; nothing in this
+// launch has touched those lines before; whatever has not landed yet still reads as a sentinel and
+// is re-read coherently).
+struct FrBlockSrc { double* base; const double* w; bool resid; };
+typedef double fr_d2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ FrBlockSrc fr_block_src(const EkfFrame& fr, int nb, int i, int tc, int lane) {
-    const int rr = lane >> 2, cg = lane & 3;
     FrBlockSrc s;
-    if (i < nb) {
-        s.p = fr.xs + ((size_t)tc * fr.sblk_rows + EKF_RB * i + rr) * 16 + 4 * cg;
-        s.live = true;
+    s.resid = i >= nb;
+    if (!s.resid) {
+        s.base = fr.xs + ((size_t)tc * fr.sblk_rows + EKF_RB * i) * 16;
+        s.w = s.base + 255;
     } else {
-        s.p = fr.xr + EKF_RB * tc + 4 * cg;
-        s.live = rr == 0;
+        s.base = fr.xr + EKF_RB * tc;
+        s.w = s.base + 15;
     }
     return s;
 }
-__device__ __forceinline__ sf64x4 fr_block_load(const FrBlockSrc& s) {
-    sf64x4 v;
-#pragma unroll
-    for (int x = 0; x < 4; ++x) v[x] = ekf_ldc(s.p + x);
+// Lane <-> word mapping of a 2 KB block: words 128 x + 2 lane, +1 (x = 0, 1), i.e. row 8x + (lane >> 3),
+// columns 2 (lane & 7), +1: two 16-byte accesses per lane, 1 KB contiguous per instruction.
+// Cacheable attempt: plain vector loads, pinned below the polling that precedes them by an opaque
+// copy of the base pointer (the compiler must not hoist them).
+__device__ __forceinline__ sf64x4 fr_block_load(const FrBlockSrc& s, int lane) {
+    sf64x4 v = {0.0, 0.0, 0.0, 0.0};
+    const double* p = s.base;
+    asm volatile("" : "+v"(p) : : "memory");
+    if (!s.resid) {
+        const fr_d2 a = *reinterpret_cast<const fr_d2*>(p + 2 * lane);
+        const fr_d2 b = *reinterpret_cast<const fr_d2*>(p + 128 + 2 * lane);
+        v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
+    } else if (lane < EKF_RB) {
+        v[0] = p[lane];
+    }
+    return v;
+}
+__device__ __forceinline__ sf64x4 fr_block_load_coherent(const FrBlockSrc& s, int lane) {
+    sf64x4 v = {0.0, 0.0, 0.0, 0.0};
+    if (!s.resid) {
+        v[0] = ekf_ldc(s.base + 2 * lane);
+        v[1] = ekf_ldc(s.base + 2 * lane + 1);
+        v[2] = ekf_ldc(s.base + 128 + 2 * lane);
+        v[3] = ekf_ldc(s.base + 128 + 2 * lane + 1);
+    } else if (lane < EKF_RB) {
+        v[0] = ekf_ldc(s.base + lane);
+    }
     return v;
 }
 __device__ __forceinline__ bool fr_block_pending(const sf64x4& v) {
     const bool p = ekf_is_sent(v[0]) || ekf_is_sent(v[1]) || ekf_is_sent(v[2]) || ekf_is_sent(v[3]);
     return __any(p);
 }
-// wait until the block is there, then re-arm it (single consumer)
-__device__ __forceinline__ sf64x4 fr_block_take(const FrBlockSrc& s, sf64x4 v, int& spin_fail) {
+// one word of the block, same address in every lane: has the producer's store landed?
+__device__ __forceinline__ bool fr_block_landed(const FrBlockSrc& s) { return !ekf_is_sent(ekf_ldc(s.w)); }
+__device__ __forceinline__ void fr_block_wait(const FrBlockSrc& s, int& spin_fail) {
+    int it = 0;
+    while (!fr_block_landed(s)) {
+        if (++it > EKF_SPIN_MAX) { spin_fail = 1; break; }
+        ekf_poll_sleep();
+    }
+}
+// the block's values are in `v` (cacheable attempt); anything still missing is re-read coherently
+__device__ __forceinline__ sf64x4 fr_block_settle(const FrBlockSrc& s, sf64x4 v, int lane, int& spin_fail) {
     int it = 0;
     while (fr_block_pending(v)) {
         if (++it > EKF_SPIN_MAX) { spin_fail = 1; break; }
         ekf_poll_sleep();
-        v = fr_block_load(s);
-    }
-    if (s.live) {
-        const double sent = ekf_sent();
-#pragma unroll
-        for (int x = 0; x < 4; ++x) ekf_stc(s.p + x, sent);
+        v = fr_block_load_coherent(s, lane);
     }
     return v;
+}
+// Re-arm (single consumer).  Issued after ALL loads of a batch have been consumed: a wait for a load
+// also waits for every older store.  Plain stores: they reach memory with the end-of-kernel
+// write-back, i.e. before the next frame's producers run.
+__device__ __forceinline__ void fr_block_rearm(const FrBlockSrc& s, int lane) {
+    const double sent = ekf_sent();
+    if (!s.resid) {
+        const fr_d2 sv = {sent, sent};
+        *reinterpret_cast<fr_d2*>(s.base + 2 * lane) = sv;
+        *reinterpret_cast<fr_d2*>(s.base + 128 + 2 * lane) = sv;
+    } else if (lane < EKF_RB) {
+        s.base[lane] = sent;
+    }
+}
+__device__ __forceinline__ sf64x4 fr_block_take(const FrBlockSrc& s, sf64x4 v, int lane, int& spin_fail) {
+    v = fr_block_settle(s, v, lane, spin_fail);
+    fr_block_rearm(s, lane);
+    return v;
+}
+__device__ __forceinline__ void fr_block_put(const sf64x4& v, double* tgt, int kp, int nb, int i, int lane) {
+    if (i < nb) {
+        const fr_d2 a = {v[0], v[1]}, b = {v[2], v[3]};
+        *reinterpret_cast<fr_d2*>(tgt + (EKF_RB * i + (lane >> 3)) * SV_CLD + 2 * (lane & 7)) = a;
+        *reinterpret_cast<fr_d2*>(tgt + (EKF_RB * i + 8 + (lane >> 3)) * SV_CLD + 2 * (lane & 7)) = b;
+    } else if (lane < EKF_RB) {
+        tgt[kp * SV_CLD + lane] = v[0];
+    }
 }
 
 __device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, int RS, double* v_sm) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
     const int kp = fr.kpad, nb = kp / EKF_RB, rows = kp + 1;
     double* ring = v_sm;                                         // [RS][rows][SV_CLD]
+    double* dscr0 = v_sm + (size_t)RS * rows * SV_CLD + 8;       // [2][16][17] Dinv of block column b (slot b & 1)
     const bool all_resident = RS >= nb;
     auto colbuf = [&](int col) { return ring + (size_t)(col % RS) * rows * SV_CLD; };
     constexpr int NW = FR_T / 64;
@@ -186,8 +306,12 @@ __device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, int RS, doubl
     double* __restrict__ xy = fr.xl + fr.xl_y;
     int nstamp = 0, spin_fail = 0;
 #define EKF_STAMP() do { if (fr.stamps && tid == 0) fr.stamps[nstamp] = clock64(); ++nstamp; } while (0)
+    if (fr.stamps && tid == 0) fr.stamps[62] = wall_clock64();
     EKF_STAMP();
     constexpr int PB = 6;
+    // block columns brought into LDS before the first pivot chain: all of them when they all stay
+    // resident (the free waves have no slack for memory round trips during the chains), else 0 and 1
+    // (column c >= 2 then arrives during iteration c - 2)
     const int ncol0 = all_resident ? nb : (nb > 1 ? 2 : 1);
     int ntot = 0;
     for (int tc = 0; tc < ncol0; ++tc) ntot += nb - tc + 1;
@@ -203,24 +327,63 @@ __device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, int RS, doubl
         pi[j] = has ? tc + u : -1;
         ptc[j] = tc;
         ps[j] = fr_block_src(fr, nb, tc + u, tc, lane);
-        pv[j] = fr_block_load(ps[j]);
     }
     EKF_STAMP();
+    {   // poll one word per block, all blocks of this wave together
+        int it = 0;
+        for (;;) {
+            bool pend = false;
+#pragma unroll
+            for (int j = 0; j < PB; ++j)
+                if (pi[j] >= 0) pend = pend | !fr_block_landed(ps[j]);      // (no short circuit: loads together)
+            if (!pend) break;
+            if (++it > EKF_SPIN_MAX) { spin_fail = 1; break; }
+            ekf_poll_sleep();
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j)
+        if (pi[j] >= 0) pv[j] = fr_block_load(ps[j], lane);
 #pragma unroll
     for (int j = 0; j < PB; ++j)
         if (pi[j] >= 0) {
-            pv[j] = fr_block_take(ps[j], pv[j], spin_fail);
-            sv_put_block(pv[j], colbuf(ptc[j]), kp, nb, pi[j], lane);
+            pv[j] = fr_block_settle(ps[j], pv[j], lane, spin_fail);
+            fr_block_put(pv[j], colbuf(ptc[j]), kp, nb, pi[j], lane);
         }
+#pragma unroll
+    for (int j = 0; j < PB; ++j)
+        if (pi[j] >= 0) fr_block_rearm(ps[j], lane);
     for (int u0 = wave + NW * PB; u0 < ntot; u0 += NW) {
         int u = u0, tc = 0;
         while (u >= nb - tc + 1) { u -= nb - tc + 1; ++tc; }
         const FrBlockSrc s = fr_block_src(fr, nb, tc + u, tc, lane);
-        sv_put_block(fr_block_take(s, fr_block_load(s), spin_fail), colbuf(tc), kp, nb, tc + u, lane);
+        fr_block_wait(s, spin_fail);
+        fr_block_put(fr_block_take(s, fr_block_load(s, lane), lane, spin_fail), colbuf(tc), kp, nb, tc + u, lane);
     }
     __syncthreads();
     EKF_STAMP();
 
+    // Publication of a finished block column (MFMA operand order, see ekf_kernels.h) by ONE wave
+    // that is not on the pivot chain's critical path, from the LDS copy: 512 contiguous bytes per
+    // store instruction, Dinv last (its last 512 bytes are what the chunks poll).
+    auto publish = [&](int pb) {
+        const double* colb = colbuf(pb);
+        const double* dscr = dscr0 + (pb & 1) * (16 * 17);
+        double dv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dv[r] = dscr[(lane & 15) * 17 + (lane >> 4) + 4 * r];
+        for (int i = pb + 1; i < nb; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                ekf_stc(xlop + sv_lop_index(i, pb) + r * 64 + lane,
+                        -colb[(size_t)(EKF_RB * i + (lane & 15)) * SV_CLD + (lane >> 4) + 4 * r]);
+        if (lane < EKF_RB) ekf_stc(xy + EKF_RB * pb + lane, colb[(size_t)kp * SV_CLD + lane]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            ekf_stc(xdop + (size_t)(pb * 4 + r) * 64 + lane, dv[r]);
+        // ring mode: this workgroup reads the column back later (sv_terms_glb): be done before the barrier
+        if (!all_resident) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
     int bad = 0;
     for (int b = 0; b < nb; ++b) {
         const int cb = EKF_RB * b;
@@ -263,14 +426,6 @@ __device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, int RS, doubl
                 }
             }
             if (live) {
-                if (row == kp) {                         // residual row: y of this block
-#pragma unroll
-                    for (int x = 0; x < EKF_RB; ++x) ekf_stc(xy + cb + x, a[x]);
-                } else if (row >= cb + EKF_RB) {         // -L block (row/16, b) in MFMA operand order
-                    const size_t base = sv_lop_index(row >> 4, b) + (row & 15);
-#pragma unroll
-                    for (int x = 0; x < EKF_RB; ++x) ekf_stc(xlop + base + (x >> 2) * 64 + 16 * (x & 3), -a[x]);
-                }
                 double* dst = cur + (size_t)row * SV_CLD;
 #pragma unroll
                 for (int x = 0; x < EKF_RB; ++x) dst[x] = a[x];
@@ -282,10 +437,15 @@ __device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, int RS, doubl
             if (ident) {                                 // a[x] = Dinv_b[x][i], i = lane - 16
                 const int i = lane - EKF_RB;
 #pragma unroll
-                for (int x = 0; x < EKF_RB; ++x) ekf_stc(xdop + (size_t)(b * 4 + (i >> 2)) * 64 + x + 16 * (i & 3), a[x]);
+                for (int x = 0; x < EKF_RB; ++x) dscr0[(b & 1) * (16 * 17) + x * 17 + i] = a[x];
             }
         } else {
-            const int fw = wave - (nrw + 2), nfw = NW - (nrw + 2);
+            const bool pubonly = NW - (nrw + 2) >= 3;           // wave NW-1 does nothing but publish
+            const int fw = wave - (nrw + 2), nfw = NW - (nrw + 2) - (pubonly ? 1 : 0);
+            if (b > 0 && wave == NW - 1) publish(b - 1);       // off the pivot chain's critical path
+            if (pubonly && wave == NW - 1) {
+                // nothing else
+            } else {
             if (b >= 1 && b + 1 < nb)
                 for (int i = b + 1 + fw; i <= nb; i += nfw) {
                     SvAcc a;
@@ -298,24 +458,28 @@ __device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, int RS, doubl
                 for (int i = tc + fw; i <= nb; i += nfw) {
                     if (!all_resident) {
                         const FrBlockSrc s = fr_block_src(fr, nb, i, tc, lane);
-                        sv_put_block(fr_block_take(s, fr_block_load(s), spin_fail), colbuf(tc), kp, nb, i, lane);
+                        fr_block_wait(s, spin_fail);
+                        fr_block_put(fr_block_take(s, fr_block_load(s, lane), lane, spin_fail), colbuf(tc), kp, nb, i, lane);
                     }
                     if (b >= 1) {
                         SvAcc a;
                         sv_acc_load(a, colbuf(tc), kp, i, c, g);
                         int q = 0;
                         for (; q < b && !(q + RS >= nb || b <= q + RS - 3); ++q) {}
-                        sv_terms_glb<true>(a, xlop, xy, nb, i, tc, q, g, lane);
+                        sv_terms_glb<false>(a, xlop, xy, nb, i, tc, q, g, lane);
                         for (; q < b; ++q) sv_term_lds(a, colbuf(q), kp, i, tc, c, g, (q & 1) != 0);
                         sv_acc_store(a, colbuf(tc), kp, i, c, g);
                     }
                 }
+            }
         }
         __syncthreads();
         EKF_STAMP();
     }
+    if (wave == NW - 1) publish(nb - 1);
     if ((bad | (spin_fail << 2)) && lane == 0) atomicOr(fr.status, bad | (spin_fail << 2));
     EKF_STAMP();
+    if (fr.stamps && tid == 0) fr.stamps[63] = wall_clock64();
 #undef EKF_STAMP
 }
 
@@ -324,38 +488,90 @@ __device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, int RS, doubl
 // ---------------------------------------------------------------------------------------------
 // right-looking blocked forward substitution on 16 columns, one wave, everything in registers.
 // t[b] starts as A_b and ends as W_b; per finished block column q of the factor:
-//   W_q = Dinv_q t[q] ;  t[i] += (-L_iq) W_q  for i > q        (same fma sequence per t[i] as the
-// left-looking stand-alone panel kernel: q ascending)
-template <typename T, int NB>
-__device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds, int wv, int col0, int lane,
-                                         int& spin_fail) {
+//   W_q = Dinv_q t[q] ;  t[i] += (-L_iq) W_q  for i > q ;  dx += W_q^T y_q
+// (same fma sequence per t[i] and for dx as the left-looking stand-alone panel kernel).
+// Only wave 0 of the workgroup polls memory for block column q (4 loads per round, so the
+// factorisation's stores are not stuck behind a storm of polls); the other waves watch an LDS word.
+template <typename T, int NB, int MODEL>
+__device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds, volatile int* sync, double* pshare,
+                                         int wv, int col0, int lane, int& spin_fail) {
     const int j = lane & 15, g = lane >> 4;
     const double* __restrict__ xlop = fr.xl;
     const double* __restrict__ xdop = fr.xl + fr.xl_dop;
     const double* __restrict__ xy = fr.xl + fr.xl_y;
+    long long* stp = (fr.stamps && col0 == 0 && lane == 0) ? fr.stamps + 34 : nullptr;
+    T* __restrict__ wp = static_cast<T*>(fr.wpanel);
     pf64x4 t[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r) t[b][r] = a_lds[(16 * b + g + 4 * r) * FR_ALD + 16 * wv + j];
+    // the old state of this wave's columns (nobody writes it before the injection below)
+    const int scol = col0 + j;
+    double st_old = 0.0, q_old[4] = {0.0, 0.0, 0.0, 0.0};
+    if (MODEL == 0) {
+        if (scol < fr.dims) st_old = fr.state[scol];
+        if (col0 == 0)
+            for (int i = 0; i < 4; ++i) q_old[i] = fr.state[3 + i];
+    }
+    double part = 0.0;
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
-        double dq[4];
+        double dq[4], yq[4];
         double lq[NB][4];
-        int it = 0;
-        for (;;) {
-            bool pend = false;
+        if (wv == 0) {
+            // sync[0] = block columns shared so far, sync[1] = reads of the shared slot acknowledged
+            int it = 0;
+            if (q < NB - 1)      // (the last block column is polled on the data itself: one round trip less)
+                while (ekf_is_sent(ekf_ldc(xdop + (size_t)(q * 4 + 3) * 64 + 63))) {      // the word written last
+                    if (++it > EKF_SPIN_MAX) { spin_fail = 1; break; }
+                    ekf_poll_sleep();
+                }
+            for (it = 0;; ++it) {
+                bool pend = false;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dq[r] = ekf_ldt(xdop + (size_t)(q * 4 + r) * 64 + lane, it > 0 || q == NB - 1);
+                    yq[r] = ekf_ldt(xy + 16 * q + g + 4 * r, it > 0 || q == NB - 1);
+                    pend = pend || ekf_is_sent(dq[r]) || ekf_is_sent(yq[r]);
+                }
+                if (!__any(pend)) break;
+                if (it > EKF_SPIN_MAX) { spin_fail = 1; break; }
+                ekf_poll_sleep();
+            }
+            it = 0;
+            while (sync[1] < 3 * q) {                  // the slot's previous content has been read
+                if (++it > 8 * EKF_SPIN_MAX) { spin_fail = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                dq[r] = ekf_ldc(xdop + (size_t)(q * 4 + r) * 64 + lane);
-                pend |= ekf_is_sent(dq[r]);
+                pshare[r * 64 + lane] = dq[r];
+                pshare[(4 + r) * 64 + lane] = yq[r];
             }
+            if (lane == 0) sync[0] = q + 1;
+        } else {
+            int it = 0;
+            while (sync[0] < q + 1) {
+                if (++it > 8 * EKF_SPIN_MAX) { spin_fail = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dq[r] = pshare[r * 64 + lane];
+                yq[r] = pshare[(4 + r) * 64 + lane];
+            }
+            if (lane == 0) atomicAdd(const_cast<int*>(sync) + 1, 1);
+        }
+        int it = 0;
+        for (;;) {      // normally one pass: the -L blocks of column q were published before Dinv
+            bool pend = false;
 #pragma unroll
             for (int i = q + 1; i < NB; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    lq[i - q - 1][r] = ekf_ldc(xlop + sv_lop_index(i, q) + r * 64 + lane);
-                    pend |= ekf_is_sent(lq[i - q - 1][r]);
+                    lq[i][r] = ekf_ldt(xlop + sv_lop_index(i, q) + r * 64 + lane, it > 0);
+                    pend = pend || ekf_is_sent(lq[i][r]);
                 }
             if (!__any(pend)) break;
             if (++it > EKF_SPIN_MAX) { spin_fail = 1; break; }
@@ -366,44 +582,50 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
         for (int r = 0; r < 4; ++r) wq = __builtin_amdgcn_mfma_f64_16x16x4f64(dq[r], t[q][r], wq, 0, 0, 0);
         t[q] = wq;
 #pragma unroll
+        for (int r = 0; r < 4; ++r) {                   // W rows of block q are final
+            const int row = 16 * q + g + 4 * r;
+            wp[(int64_t)row * fr.ldw + col0 + j] = (T)wq[r];
+            if (fr.wdbg) fr.wdbg[(int64_t)row * fr.ldw + col0 + j] = wq[r];
+        }
+#pragma unroll
         for (int i = q + 1; i < NB; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                t[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(lq[i - q - 1][r], wq[r], t[i], 0, 0, 0);
+                t[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(lq[i][r], wq[r], t[i], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part += wq[r] * yq[r];
+        if (stp) stp[q] = wall_clock64();
     }
-    // y = L^-1 (z - h): complete once the last block column is
-    double yv[NB][4];
-    {
-        int it = 0;
-        for (;;) {
-            bool pend = false;
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    yv[b][r] = ekf_ldc(xy + 16 * b + g + 4 * r);
-                    pend |= ekf_is_sent(yv[b][r]);
-                }
-            if (!__any(pend)) break;
-            if (++it > EKF_SPIN_MAX) { spin_fail = 1; break; }
-            ekf_poll_sleep();
-        }
-    }
-    T* __restrict__ wp = static_cast<T*>(fr.wpanel);
-    double part = 0.0;
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 16 * b + g + 4 * r;
-            const double v = t[b][r];
-            part += v * yv[b][r];
-            wp[(int64_t)row * fr.ldw + col0 + j] = (T)v;
-            if (fr.wdbg) fr.wdbg[(int64_t)row * fr.ldw + col0 + j] = v;
-        }
     part += __shfl_xor(part, 16);
-    part += __shfl_xor(part, 32);
-    if (g == 0) ekf_stc(fr.dxvec + col0 + j, part);
+    part += __shfl_xor(part, 32);                    // dx[col0 + j] in every lane group
+    const int col = col0 + j;
+    if (MODEL == 1) {               // every landmark has a quaternion: injected by the last chunk
+        if (g == 0) ekf_stc(fr.dxvec + col, part);
+    } else {
+        // extended_kalman_filter.py:133-152.  Nobody reads the state any more: its only readers
+        // in this launch are the S-block workgroups, which the factorisation has waited for.
+        double nv = 0.0;
+        if (g == 0 && (col < 3 || (col >= EKF_CAM && col < fr.dims))) {
+            nv = st_old + part;
+            fr.state[col] = nv;
+        }
+        if (col0 == 0) {
+            const double e0 = __shfl(part, 7), e1 = __shfl(part, 8), e2 = __shfl(part, 9);
+            const double x0 = __shfl(nv, 0), x1 = __shfl(nv, 1), x2 = __shfl(nv, 2);
+            if (lane == 0) {
+                double qv[4] = {q_old[0], q_old[1], q_old[2], q_old[3]};
+                const double err[3] = {e0, e1, e2};
+                ekf_quat_inject(qv, err, fr.quat_mode);
+                for (int i = 0; i < 4; ++i) fr.state[3 + i] = qv[i];
+                for (int i = 0; i < 3; ++i) fr.state[7 + i] = 0.0;   // :152
+                if (fr.traj_row) {
+                    fr.traj_row[0] = x0; fr.traj_row[1] = x1; fr.traj_row[2] = x2;
+                    for (int i = 0; i < 4; ++i) fr.traj_row[3 + i] = qv[i];
+                }
+            }
+        }
+    }
+    if (stp) stp[NB] = wall_clock64();
 }
 
 template <typename T, int NU, int MODEL>
@@ -413,19 +635,19 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
     double* hs = sm;                                    // [k][JC]
     double* a_lds = sm + fr.k * JC;                     // [kpad][FR_ALD]
     int* lmc = reinterpret_cast<int*>(a_lds + (size_t)fr.kpad * FR_ALD);
-    int* flag = lmc + 64;
+    int* flag = lmc + 64;                               // [0] last-chunk flag, [1..2] panel sync words
+    double* pshare = reinterpret_cast<double*>(lmc + 72);   // [8][64] Dinv operands and y of one block column
     const int tid = threadIdx.x, m = fr.m;
     const int chunk0 = chunk * 64, cl = tid & 63, c = chunk0 + cl, g = tid >> 6;
     const T* __restrict__ P = static_cast<const T*>(fr.cov);
     const T* __restrict__ prow = static_cast<const T*>(fr.prow);
     const int64_t ld = fr.ld;
+    if (fr.stamps && chunk == 0 && tid == 0) fr.stamps[32] = wall_clock64();
     T pcr[EKF_CAM];
 #pragma unroll
     for (int a = 0; a < EKF_CAM; ++a) pcr[a] = prow ? prow[(int64_t)a * fr.ldw + c] : P[a * ld + c];
-    double cam[EKF_CAM];
-#pragma unroll
-    for (int a = 0; a < EKF_CAM; ++a) cam[a] = fr.state[a];
     if (tid < m) lmc[tid] = EKF_CAM + LMD * fr.idx[tid];
+    if (tid == 0) { flag[1] = 0; flag[2] = 0; }
     __syncthreads();
     T plr[NU][LMD];
 #pragma unroll
@@ -436,7 +658,32 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
         for (int d = 0; d < LMD; ++d)
             plr[u][d] = prow ? prow[(int64_t)(EKF_CAM + LMD * ju + d) * fr.ldw + c] : P[(int64_t)(c0 + d) * ld + c];
     }
-    fr_measure<MODEL>(fr, cam, lmc, hs, tid, false);
+    // Jacobian rows: published by S-block workgroup 0 (this role never reads the state, so the
+    // injection at the end of the launch cannot race with a chunk that starts late)
+    {
+        const double* __restrict__ xj = fr.xl + fr.xl_jac;
+        const int nel = fr.k * JC;
+        int spin = 0;
+        if (tid < 64) {        // one wave polls one word (the last one written)
+            int it = 0;
+            while (ekf_is_sent(ekf_ldc(xj + nel - 1))) {
+                if (++it > EKF_SPIN_MAX) { spin = 1; break; }
+                ekf_poll_sleep();
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < nel; e += FR_T) {
+            double v = ekf_ldw(xj + e);
+            int it = 0;
+            while (ekf_is_sent(v)) {
+                if (++it > EKF_SPIN_MAX) { spin = 1; break; }
+                ekf_poll_sleep();
+                v = ekf_ldc(xj + e);
+            }
+            hs[e] = v;
+        }
+        if (spin) atomicOr(fr.status, 4);
+    }
     __syncthreads();
     double pc[EKF_CAM];
 #pragma unroll
@@ -465,19 +712,23 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
     }
     for (int r = fr.k + g; r < fr.kpad; r += NWV) a_lds[r * FR_ALD + cl] = 0.0;
     __syncthreads();
+    if (fr.stamps && chunk == 0 && tid == 0) fr.stamps[33] = wall_clock64();
     int spin_fail = 0;
     if (g < 4) {
         const int lane = tid & 63, col0 = chunk0 + 16 * g;
         switch (fr.kpad / EKF_RB) {
-#define FR_CASE(NB) case NB: fr_panel<T, NB>(fr, a_lds, g, col0, lane, spin_fail); break;
+#define FR_CASE(NB) case NB: fr_panel<T, NB, MODEL>(fr, a_lds, flag + 1, pshare, g, col0, lane, spin_fail); break;
             FR_CASE(1) FR_CASE(2) FR_CASE(3) FR_CASE(4) FR_CASE(5) FR_CASE(6)
             FR_CASE(7) FR_CASE(8) FR_CASE(9) FR_CASE(10) FR_CASE(11)
-            default: fr_panel<T, 12>(fr, a_lds, g, col0, lane, spin_fail); break;
+            default: fr_panel<T, 12, MODEL>(fr, a_lds, flag + 1, pshare, g, col0, lane, spin_fail); break;
 #undef FR_CASE
         }
         if (spin_fail && (tid & 63) == 0) atomicOr(fr.status, 4);
     }
-    // dx of this chunk has to be in memory before the chunk is counted as done
+    if (MODEL == 0) return;
+    // ---- EKF_Rotations: dx of this chunk has to be in memory before the chunk counts as done;
+    // the last chunk injects (ekf_with_rotations.py:142-177): camera and every landmark: xyz
+    // additive, quaternion multiplicative (scalar first); landmark error states are never written
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
@@ -487,46 +738,21 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
     }
     __syncthreads();
     if (!flag[0]) return;
-    // ---- last chunk: state injection (every workgroup has read the old state by now)
-    if (MODEL == 0) {
-        // extended_kalman_filter.py:133-152: xyz and every landmark additive, dx[3:7] dropped,
-        // quaternion from the error state, error state reset
-        for (int col = EKF_CAM + tid; col < fr.dims; col += FR_T) fr.state[col] = fr.state[col] + ekf_ldc(fr.dxvec + col);
-        if (tid == 0) {
-            double x[3];
-            for (int i = 0; i < 3; ++i) {
-                x[i] = fr.state[i] + ekf_ldc(fr.dxvec + i);
-                fr.state[i] = x[i];
-            }
-            double q[4] = {fr.state[3], fr.state[4], fr.state[5], fr.state[6]};
-            const double err[3] = {ekf_ldc(fr.dxvec + 7), ekf_ldc(fr.dxvec + 8), ekf_ldc(fr.dxvec + 9)};
-            ekf_quat_inject(q, err, fr.quat_mode);
-            for (int i = 0; i < 4; ++i) fr.state[3 + i] = q[i];
-            for (int i = 0; i < 3; ++i) fr.state[7 + i] = 0.0;
+    for (int i = tid; i <= fr.n_lm; i += FR_T) {
+        const int c0 = (i == 0) ? 0 : EKF_CAM + 10 * (i - 1);
+        double* st = fr.state + c0;
+        const double* dx = fr.dxvec + c0;
+        double q[4] = {st[3], st[4], st[5], st[6]};
+        const double err[3] = {ekf_ldc(dx + 7), ekf_ldc(dx + 8), ekf_ldc(dx + 9)};
+        ekf_quat_inject(q, err, 1);
+        const double x0 = st[0] + ekf_ldc(dx + 0), x1 = st[1] + ekf_ldc(dx + 1), x2 = st[2] + ekf_ldc(dx + 2);
+        st[0] = x0; st[1] = x1; st[2] = x2;
+        for (int e = 0; e < 4; ++e) st[3 + e] = q[e];
+        if (i == 0) {
+            for (int e = 0; e < 3; ++e) st[7 + e] = 0.0;
             if (fr.traj_row) {
-                for (int i = 0; i < 3; ++i) fr.traj_row[i] = x[i];
-                for (int i = 0; i < 4; ++i) fr.traj_row[3 + i] = q[i];
-            }
-        }
-    } else {
-        // ekf_with_rotations.py:142-177: camera and every landmark: xyz additive, quaternion
-        // multiplicative (scalar first); the landmarks' error states are never written
-        for (int i = tid; i <= fr.n_lm; i += FR_T) {
-            const int c0 = (i == 0) ? 0 : EKF_CAM + 10 * (i - 1);
-            double* st = fr.state + c0;
-            const double* dx = fr.dxvec + c0;
-            double q[4] = {st[3], st[4], st[5], st[6]};
-            const double err[3] = {ekf_ldc(dx + 7), ekf_ldc(dx + 8), ekf_ldc(dx + 9)};
-            ekf_quat_inject(q, err, 1);
-            const double x0 = st[0] + ekf_ldc(dx + 0), x1 = st[1] + ekf_ldc(dx + 1), x2 = st[2] + ekf_ldc(dx + 2);
-            st[0] = x0; st[1] = x1; st[2] = x2;
-            for (int e = 0; e < 4; ++e) st[3 + e] = q[e];
-            if (i == 0) {
-                for (int e = 0; e < 3; ++e) st[7 + e] = 0.0;
-                if (fr.traj_row) {
-                    fr.traj_row[0] = x0; fr.traj_row[1] = x1; fr.traj_row[2] = x2;
-                    for (int e = 0; e < 4; ++e) fr.traj_row[3 + e] = q[e];
-                }
+                fr.traj_row[0] = x0; fr.traj_row[1] = x1; fr.traj_row[2] = x2;
+                for (int e = 0; e < 4; ++e) fr.traj_row[3 + e] = q[e];
             }
         }
     }
@@ -537,9 +763,10 @@ __global__ __launch_bounds__(FR_T) void ekf_front_kernel(EkfFrame fr, int RS) {
     extern __shared__ __attribute__((aligned(16))) double fr_sm[];
     const int nb = fr.kpad / EKF_RB, nS = nb * (nb + 1) / 2;
     const int bx = blockIdx.x;
-    if (bx < nS) fr_role_sblock<T, MODEL>(fr, bx, nS, fr_sm);
-    else if (bx == nS) fr_role_factor(fr, RS, fr_sm);
-    else fr_role_chunk<T, NU, MODEL>(fr, bx - nS - 1, fr_sm);
+    if (bx == 0) fr_role_measure<MODEL>(fr, fr_sm);
+    else if (bx <= nS) fr_role_sblock<T, MODEL>(fr, bx - 1, nS, fr_sm);
+    else if (bx == nS + 1) fr_role_factor(fr, RS, fr_sm);
+    else fr_role_chunk<T, NU, MODEL>(fr, bx - nS - 2, fr_sm);
 }
 
 template <typename T, int NU, int MODEL>
@@ -553,12 +780,12 @@ static void ekf_front_go(const EkfFrame& fr, hipStream_t s) {
         once = true;
     }
     const int nb = fr.kpad / EKF_RB, nS = nb * (nb + 1) / 2;
-    const size_t lds_s = ((size_t)fr.k * JC + NSLOT * 16) * 8 + 64 * 4 + 16;
-    const size_t lds_c = ((size_t)fr.k * JC + (size_t)fr.kpad * FR_ALD) * 8 + 64 * 4 + 16;
-    const size_t lds_f = (size_t)ekf_solve_stream_lds_bytes(fr.kpad, fr.k);
+    const size_t lds_s = ((size_t)fr.k * JC + NSLOT * 16 + 32 + fr.kpad) * 8 + 16;
+    const size_t lds_c = ((size_t)fr.k * JC + (size_t)fr.kpad * FR_ALD) * 8 + 72 * 4 + 8 * 64 * 8 + 16;
+    const size_t lds_f = (size_t)ekf_solve_stream_lds_bytes(fr.kpad, fr.k) + 2 * 16 * 17 * 8;
     size_t lds = lds_s > lds_c ? lds_s : lds_c;
     if (lds_f > lds) lds = lds_f;
-    hipLaunchKernelGGL((ekf_front_kernel<T, NU, MODEL>), dim3(nS + 1 + fr.ncols / 64), dim3(FR_T), lds, s, fr,
+    hipLaunchKernelGGL((ekf_front_kernel<T, NU, MODEL>), dim3(nS + 2 + fr.ncols / 64), dim3(FR_T), lds, s, fr,
                        ekf_solve_stream_ring(fr.kpad, fr.k));
 }
 

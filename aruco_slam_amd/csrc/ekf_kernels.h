@@ -55,9 +55,9 @@ struct EkfFrame {
     // fused front kernel (ekf_front.hip): exchange buffers between its workgroups
     double* xs;                // S blocks, layout of sblk; sentinel-armed, re-armed by the consumer
     double* xr;                // [kmax] z - h (0 for rows k..kpad-1)
-    double* xl;                // this frame's factor exchange: [-L operands | Dinv operands | y]
+    double* xl;                // this frame's exchange: [-L operands | Dinv operands | y | Jacobian rows [k][JC]]
     double* xl_next;           // the other buffer, re-armed during this frame for the next one
-    int32_t xl_dop, xl_y;      // offsets (doubles) of the Dinv operands and of y inside xl
+    int32_t xl_dop, xl_y, xl_jac;   // offsets (doubles) of the Dinv operands, y and the Jacobian rows inside xl
     int32_t xl_len;            // doubles per buffer
     int32_t n_lm;              // landmarks in the state (model 1 injection)
     unsigned long long* done_ctr;      // chunks finished since reset (device)

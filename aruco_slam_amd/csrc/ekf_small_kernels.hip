@@ -188,7 +188,7 @@ template void ekf_launch_gather<double>(const EkfFrame&, hipStream_t);
 // number of block columns resident in LDS: all of them when they fit (kpad <= 128), else a ring
 int ekf_solve_stream_ring(int kpad, int k) {
     const size_t col = (size_t)(kpad + 1) * SV_CLD * sizeof(double);
-    const size_t fixed = 8 * sizeof(double);
+    const size_t fixed = (8 + 2 * 16 * 17) * sizeof(double);     // + Dinv scratch of the fused front kernel
     (void)k;
     int rs = (int)((160 * 1024 - fixed) / col);
     const int nb = kpad / EKF_RB;

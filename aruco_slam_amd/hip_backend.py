@@ -129,6 +129,7 @@ class HipEkf:
         cfg.flags = {None: 0, False: 1, True: 2}[lookahead]   # None = automatic
         if not fused:
             cfg.flags |= 4        # separate gather / solve / panel launches
+        self.fused = bool(fused)
         cfg.model = {"ekf": 0, "ekf_rotations": 1}[model]
         self.lm_dims, self.rows_per_detection = (10, 7) if cfg.model == 1 else (3, 3)
         for key, val in (noise or {}).items():
@@ -249,6 +250,8 @@ class HipEkf:
             us, cnt = C.c_double(), C.c_int64()
             self._check(self.lib.ekf_get_kernel_timing(self.h, i, C.byref(us), C.byref(cnt)))
             out[name] = (us.value, cnt.value)
+        if self.fused:       # one launch: slot 0 is the whole front kernel, slots 1-2 are empty gaps
+            out = {"front": out["gather"], "cov_update": out["cov_update"]}
         return out
 
     def debug_enable_w(self):

@@ -1,0 +1,23 @@
+import sys; sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+import numpy as np
+from aruco_slam_amd.filters.extended_kalman_filter import EKF
+from aruco_slam_amd.synthetic import SyntheticStream
+n,m=1024,32
+s=SyntheticStream(n,m,seed=0)
+f=EKF(np.array([0,0,0,1,0,0,0,0,0,0]),max_landmarks=n,max_visible=m,cov_dtype="float32")
+f.backend.debug_enable_w()
+for ids,p in s.bootstrap(): f.observe(ids,p)
+for ids,p in s.steady(5): f.observe(ids,p)
+st=f.backend.debug_fetch("stamps",m)
+nb=6
+t0=min(st[62],st[32],st[60])
+us=lambda i:(st[i]-t0)/100.0
+print("fused front kernel timeline, us since the earliest stamp (100 MHz wall clock)")
+print("S-block wg0 start",us(60),"  measure wg published",us(55),"  S-block wg nS-1 stored",us(61))
+print("factor: start",us(62)," end",us(63))
+d=np.diff(st[:4+2*nb])
+print("  phases in shader cycles: issue",d[0]," S into LDS",d[1])
+for b in range(nb): print("  col",b," (A)",d[2+2*b]," pivot chain",d[3+2*b])
+print("chunk0: start",us(32)," A in LDS",us(33))
+for q in range(nb): print("  step",q,"done",us(34+q))
+print("  W/dx stored",us(34+nb))
