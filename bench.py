@@ -47,6 +47,8 @@ def parse_args():
     ap.add_argument("--visible", type=int, default=32)
     ap.add_argument("--cov-dtype", default="float32", choices=["float32", "float64"])
     ap.add_argument("--cov-kernel", default="auto", choices=["auto", "valu", "mfma"])
+    ap.add_argument("--lookahead", choices=["auto", "on", "off"], default="auto",
+                    help="cross-frame lookahead of the sequence entry point (auto = off)")
     ap.add_argument("--unfused", action="store_true",
                     help="gather / solve / panel as separate launches instead of the fused front kernel")
     ap.add_argument("--cpu-frames", type=int, default=12,
@@ -116,7 +118,8 @@ def main():
 
     # ---- untimed: filter, bootstrap through observe(), resident detections --
     flt = EKF(INIT_POSE, max_landmarks=n, max_visible=m, cov_dtype=args.cov_dtype,
-              cov_kernel=args.cov_kernel, device=dev, fused=not args.unfused)
+              cov_kernel=args.cov_kernel, device=dev, fused=not args.unfused,
+              lookahead={"auto": None, "on": True, "off": False}[args.lookahead])
     from aruco_slam_amd.sequences import rank_seed
     stream = SyntheticStream(n, m, seed=rank_seed(0, rank))
     for ids, poses in stream.bootstrap():

@@ -64,9 +64,9 @@ typedef struct ekf_config {
     int32_t cov_kernel;     /* EKF_COVK_*: covariance-update kernel */
     int32_t model;          /* EKF_MODEL_* */
     int32_t reserved;
-    int32_t flags;          /* cross-frame lookahead of ekf_observe_sequence_device: 0 = automatic
-                             * (on when 3n+10 >= 6144, where the big update dominates), bit 0 = never,
-                             * bit 1 = always.  bit 2: run gather / solve / panel as three separate
+    int32_t flags;          /* bit 1: cross-frame lookahead in ekf_observe_sequence_device (priority rows +
+                             * covariance update on a second stream; same results, currently slower than
+                             * the serial order at every size, off by default; bit 0 is ignored).  bit 2: run gather / solve / panel as three separate
                              * launches instead of the fused front kernel (same results, bit for bit) */
     /* noise constants, defaults = extended_kalman_filter.py:21-27 */
     double initial_camera_uncertainty;   /* 0.1  */
