@@ -275,8 +275,12 @@ int sync_and_check(ekf_filter* f) {
     int32_t st = 0;
     HIP_TRY(hipMemcpy(&st, f->at<int32_t>(f->lay.off_status), sizeof(st), hipMemcpyDeviceToHost));
     static const bool ignore = getenv("EKF_IGNORE_NUMERIC") != nullptr;   // timing ablations only
-    if (st != 0 && !ignore)
+    if (st != 0 && !ignore) {
+        if (st & 4)   // a bounded wait inside the fused front kernel ran out (should never happen)
+            return fail(EKF_ERR_NUMERIC, "internal: exchange wait timed out in the front kernel (status " +
+                                             std::to_string(st) + ")");
         return fail(EKF_ERR_NUMERIC, "innovation covariance S was not positive definite");
+    }
     return EKF_OK;
 }
 

@@ -93,77 +93,119 @@ __device__ __forceinline__ void ekf_tri_decode(int item, int& I, int& J) {
 }
 
 // --------------------------------------------------------------------------
-// MFMA f32: one wave per 32x32 lower tile
+// MFMA f32: one wave per 32x32 lower tile, v_mfma_f32_32x32x2_f32 over k in ascending order.
+// Both operands come straight from the L2-resident k-major W panel (no LDS staging, no barriers)
+// through a ring of D = 3 register slots of 8 k-pairs, so a wave needs < 96 registers and FIVE
+// waves fit a SIMD: every tile of the n=1024 problem (18.6 per CU) is resident from the start and
+// the launch runs as one round (the earlier version held all 96 operands in registers: 132
+// registers, 3 waves per SIMD, ~1.3 rounds, 19.3 us instead of 15.9).
 // --------------------------------------------------------------------------
-// KB = kpad / 16: the operand stream is fully unrolled so that the compiler can put every
-// load of the W panel in flight before the first MFMA.
-template <int KB>
-__global__ __launch_bounds__(256) void ekf_cov_update_mfma_f32(EkfFrame fr, int nitems) {
+template <int KB, int DMAX = 3, int WPE = 5>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+void ekf_cov_update_mfma_f32(EkfFrame fr, int nitems) {
     __shared__ float tr[4][32][33];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int item = blockIdx.x * 4 + wave;
-    if (item >= nitems) return;                       // wave-uniform, no barriers below
+    const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+    if (item >= nitems) return;
     int I, J;
     ekf_tri_decode(item, I, J);
     const int i0 = 32 * I, j0 = 32 * J;
     const float* __restrict__ wp = static_cast<const float*>(fr.wpanel);
     float* __restrict__ P = static_cast<float*>(fr.cov);
-    const int64_t ld = fr.ld, ldw = fr.ldw;
-
-    // C/D layout of 32x32x2: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-    float pt[16];
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int row = i0 + (reg & 3) + 8 * (reg >> 2) + 4 * lhi;
-        pt[reg] = P[(int64_t)row * ld + j0 + l31];
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    const int ld = (int)fr.ld, ldw = (int)fr.ldw;
+    constexpr int NCH = KB, D = (NCH < DMAX) ? NCH : DMAX;
+    float ra[D][8], rb[D][8], pt[16];
+    // Loads are written as inline asm (scalar base + one 32-bit lane offset, no 64-bit address
+    // registers) with hand-counted s_waitcnt: hipcc's own allocation at this register budget spills
+    // freshly loaded operands, which serialises the ring.
+    // Issue order: W chunks 0 .. D-1, the P tile (the HBM stream starts at once, but the first MFMAs
+    // do not wait for it), then chunk c + D after the MFMAs of chunk c.
+    const unsigned wlane = 4u * (unsigned)(lhi * ldw + l31);        // A[i = l31][k = lhi], B[k = lhi][j = l31]
+    const unsigned plane = 4u * (unsigned)(4 * lhi * ld + l31);     // C/D layout: row (reg&3) + 8 (reg>>2) + 4 lhi
+    const uint64_t kstep = 8ull * (uint64_t)ldw;                    // two rows of W in bytes
+    uint64_t ua = reinterpret_cast<uint64_t>(wp + i0), ub = reinterpret_cast<uint64_t>(wp + j0);
+    float* __restrict__ ptile = P + (int64_t)i0 * ld + j0;
+#define EKF_GLD(dst, voff, sbase) asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory")
+#define EKF_WAIT16(n, A, B)                                                                              \
+    asm volatile("s_waitcnt vmcnt(%16)"                                                                   \
+                 : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4]), "+v"(A[5]), "+v"(A[6]), "+v"(A[7]), \
+                   "+v"(B[0]), "+v"(B[1]), "+v"(B[2]), "+v"(B[3]), "+v"(B[4]), "+v"(B[5]), "+v"(B[6]), "+v"(B[7])  \
+                 : "n"(n))
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    // A[i = l31][k = lhi] = -W[k][i0 + l31],  B[k = lhi][j = l31] = W[k][j0 + l31]
-    const float* wa = wp + (int64_t)lhi * ldw + i0 + l31;
-    const float* wb = wp + (int64_t)lhi * ldw + j0 + l31;
-    // super-batches of <= 48 k-pairs: every operand load of the batch (and, in the first
-    // batch, the P tile) is in flight before the first MFMA; hipcc's own schedule is
-    // load -> wait -> mfma per step, so the order is pinned with sched_barrier.
-    constexpr int SB = (KB <= 6) ? 8 * KB : 8 * ((KB + 1) / 2);     // k-pairs per super-batch
 #pragma unroll
-    for (int k0 = 0; k0 < 8 * KB; k0 += SB) {
-        float a[SB], b[SB];
+    for (int c = 0; c < D; ++c) {
 #pragma unroll
-        for (int u = 0; u < SB; ++u) {
-            const int kk = min(k0 + u, 8 * KB - 1);
-            a[u] = wa[(int64_t)(2 * kk) * ldw];
-            b[u] = wb[(int64_t)(2 * kk) * ldw];
+        for (int u = 0; u < 8; ++u) {
+            EKF_GLD(ra[c][u], wlane, ua);
+            EKF_GLD(rb[c][u], wlane, ub);
+            ua += kstep;
+            ub += kstep;
+        }
+    }
+    {
+        uint64_t pb = reinterpret_cast<uint64_t>(ptile);
+        const uint64_t r1 = 4ull * (uint64_t)ld, r5 = 20ull * (uint64_t)ld;   // bytes: +1 row, +5 rows
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {         // rows (reg&3) + 8 (reg>>2)
+            EKF_GLD(pt[reg], plane, pb);
+            pb += ((reg & 3) == 3) ? r5 : r1;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        // loads that may still be in flight when chunk c is needed (issued after it)
+        const int later = (c < NCH - D) ? c : NCH - D;                           // chunks D .. issued so far
+        const int allow = (c < D) ? 16 * (D - c - 1) + 16 + 16 * later : 16 * (D + later - c - 1);
+        switch (allow) {      // (immediate operand; the counter saturates at 63)
+            case 0: EKF_WAIT16(0, ra[c % D], rb[c % D]); break;
+            case 16: EKF_WAIT16(16, ra[c % D], rb[c % D]); break;
+            case 32: EKF_WAIT16(32, ra[c % D], rb[c % D]); break;
+            case 48: EKF_WAIT16(48, ra[c % D], rb[c % D]); break;
+            default: EKF_WAIT16(63, ra[c % D], rb[c % D]); break;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-ra[c % D][u], rb[c % D][u], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + D < NCH) {                       // next chunk into the slot just freed
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                EKF_GLD(ra[c % D][u], wlane, ua);
+                EKF_GLD(rb[c % D][u], wlane, ub);
+                ua += kstep;
+                ub += kstep;
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < SB; ++u)
-            if (k0 + u < 8 * KB) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-a[u], b[u], acc, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
     }
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(pt[0]), "+v"(pt[1]), "+v"(pt[2]), "+v"(pt[3]), "+v"(pt[4]), "+v"(pt[5]), "+v"(pt[6]), "+v"(pt[7]),
+                   "+v"(pt[8]), "+v"(pt[9]), "+v"(pt[10]), "+v"(pt[11]), "+v"(pt[12]), "+v"(pt[13]), "+v"(pt[14]), "+v"(pt[15]));
+#undef EKF_GLD
+#undef EKF_WAIT16
     const float qlane = (I == J) ? (float)ekf_qdiag(i0 + l31, fr.dims, fr.nz) : 0.0f;
     float out[16];
+    auto stf = [](float* base, unsigned off, float v) { *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off) = v; };
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         const int rl = (reg & 3) + 8 * (reg >> 2) + 4 * lhi;
         const float v = (pt[reg] + ((rl == l31) ? qlane : 0.0f)) + acc[reg];
         out[reg] = v;
-        P[(int64_t)(i0 + rl) * ld + j0 + l31] = v;
+        stf(ptile + (int64_t)((reg & 3) + 8 * (reg >> 2)) * ld, plane, v);
     }
     if (I != J) {
-        // mirror: D^T -> tile (J, I), transposed through wave-private LDS
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg)
             tr[wave][(reg & 3) + 8 * (reg >> 2) + 4 * lhi][l31] = out[reg];
         __builtin_amdgcn_wave_barrier();
+        float* __restrict__ pm = P + (int64_t)j0 * ld + i0;
+        const unsigned mlane = 4u * (unsigned)(lhi * ld + l31);
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int c = 2 * it + lhi;               // column of D = row of D^T
-            P[(int64_t)(j0 + c) * ld + i0 + l31] = tr[wave][l31][c];
-        }
+        for (int it = 0; it < 16; ++it)          // column 2 it + lhi of D = row of D^T
+            stf(pm + (int64_t)(2 * it) * ld, mlane, tr[wave][l31][2 * it + lhi]);
     }
 }
 
@@ -302,10 +344,13 @@ void ekf_launch_cov_update<float>(const EkfFrame& fr, int variant, hipStream_t s
         const int items = ekf_tri_items(fr);
         const dim3 grid((items + 3) / 4), block(256);
         switch (fr.kpad / 16) {
-#define EKF_COV_CASE(KB) case KB: hipLaunchKernelGGL(ekf_cov_update_mfma_f32<KB>, grid, block, 0, s, fr, items); break;
+            // The kernel counts its own loads (s_waitcnt by hand), so it must not spill: 5 waves per SIMD
+            // (96 registers) up to k = 128, 4 waves (128 registers) above, where hipcc needs a few more
+            // (tests/test_host_cpu.py checks the spill count of every instantiation).
+#define EKF_COV_CASE(KB) case KB: hipLaunchKernelGGL((ekf_cov_update_mfma_f32<KB, 3, (KB <= 8) ? 5 : 4>), grid, block, 0, s, fr, items); break;
             EKF_COV_CASE(1) EKF_COV_CASE(2) EKF_COV_CASE(3) EKF_COV_CASE(4) EKF_COV_CASE(5) EKF_COV_CASE(6)
             EKF_COV_CASE(7) EKF_COV_CASE(8) EKF_COV_CASE(9) EKF_COV_CASE(10) EKF_COV_CASE(11)
-            default: hipLaunchKernelGGL(ekf_cov_update_mfma_f32<12>, grid, block, 0, s, fr, items); break;
+            default: hipLaunchKernelGGL((ekf_cov_update_mfma_f32<12, 3, 4>), grid, block, 0, s, fr, items); break;
 #undef EKF_COV_CASE
         }
     }

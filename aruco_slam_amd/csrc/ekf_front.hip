@@ -271,11 +271,12 @@ __device__ __forceinline__ sf64x4 fr_block_settle(const FrBlockSrc& s, sf64x4 v,
 __device__ __forceinline__ void fr_block_rearm(const FrBlockSrc& s, int lane) {
     const double sent = ekf_sent();
     if (!s.resid) {
-        const fr_d2 sv = {sent, sent};
-        *reinterpret_cast<fr_d2*>(s.base + 2 * lane) = sv;
-        *reinterpret_cast<fr_d2*>(s.base + 128 + 2 * lane) = sv;
+        ekf_stc(s.base + 2 * lane, sent);
+        ekf_stc(s.base + 2 * lane + 1, sent);
+        ekf_stc(s.base + 128 + 2 * lane, sent);
+        ekf_stc(s.base + 128 + 2 * lane + 1, sent);
     } else if (lane < EKF_RB) {
-        s.base[lane] = sent;
+        ekf_stc(s.base + lane, sent);
     }
 }
 __device__ __forceinline__ sf64x4 fr_block_take(const FrBlockSrc& s, sf64x4 v, int lane, int& spin_fail) {
@@ -466,7 +467,8 @@ __device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, int RS, doubl
                         sv_acc_load(a, colbuf(tc), kp, i, c, g);
                         int q = 0;
                         for (; q < b && !(q + RS >= nb || b <= q + RS - 3); ++q) {}
-                        sv_terms_glb<false>(a, xlop, xy, nb, i, tc, q, g, lane);
+                        // coherent loads: a chunk on this XCD may have pulled a half-published copy of these lines into the L2
+                        sv_terms_glb<true>(a, xlop, xy, nb, i, tc, q, g, lane);
                         for (; q < b; ++q) sv_term_lds(a, colbuf(q), kp, i, tc, c, g, (q & 1) != 0);
                         sv_acc_store(a, colbuf(tc), kp, i, c, g);
                     }
@@ -541,26 +543,30 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
             }
             it = 0;
             while (sync[1] < 3 * q) {                  // the slot's previous content has been read
-                if (++it > 8 * EKF_SPIN_MAX) { spin_fail = 1; break; }
+                if (++it > 64 * EKF_SPIN_MAX) { spin_fail = 1; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 pshare[r * 64 + lane] = dq[r];
                 pshare[(4 + r) * 64 + lane] = yq[r];
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the slot before the word that announces it
             if (lane == 0) sync[0] = q + 1;
         } else {
             int it = 0;
             while (sync[0] < q + 1) {
-                if (++it > 8 * EKF_SPIN_MAX) { spin_fail = 1; break; }
+                if (++it > 64 * EKF_SPIN_MAX) { spin_fail = 1; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 dq[r] = pshare[r * 64 + lane];
                 yq[r] = pshare[(4 + r) * 64 + lane];
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the reads before the acknowledgement
             if (lane == 0) atomicAdd(const_cast<int*>(sync) + 1, 1);
         }
         int it = 0;

@@ -210,3 +210,21 @@ def test_euler_xyz_to_quat_matches_pinned_oracle():
     want = np.stack([quat_from_euler_xyz(a) for a in ang])
     assert np.abs(got - want).max() <= 1e-15
     assert np.abs(np.linalg.norm(got, axis=1) - 1.0).max() <= 1e-15
+
+
+def test_hand_counted_kernels_do_not_spill(tmp_path):
+    """ekf_cov_update_mfma_f32 issues its loads as inline asm and counts them for s_waitcnt by hand: a
+    register spill (scratch traffic on the same counter) would silently break the counting."""
+    import re
+    import subprocess
+    from aruco_slam_amd import _build
+    src = _build.CSRC / "ekf_cov_update.hip"
+    out = tmp_path / "cov.s"
+    subprocess.run([_build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                    str(src), "-o", str(out)], check=True, capture_output=True)
+    text = out.read_text()
+    kernels = re.findall(r"\.name:\s+(\S*ekf_cov_update_mfma_f32\S*)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text)
+    assert len(kernels) >= 12
+    assert all(int(spills) == 0 for _, spills in kernels), kernels
+    scratch = re.findall(r"\.name:\s+(\S*ekf_cov_update_mfma_f32\S*)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", text)
+    assert all(int(b) == 0 for _, b in scratch), scratch
