@@ -43,7 +43,7 @@ struct Layout {
     size_t elem;      // sizeof(cov element)
     size_t off_jac, off_resid, off_y, off_lmcol, off_amat, off_sblk, off_lmat, off_dinv, off_lop, off_dop, off_wpanel, off_wpanel2, off_prow, off_wdbg,
         off_idx, off_z, off_status, off_stamps, off_dx, off_diag, off_xyz, off_unc,
-        off_xs, off_xr, off_xl, off_done, total;
+        off_xs, off_xr, off_xl, off_done, off_log, total;
     size_t xs_len, xl_len, xl_dop, xl_y, xl_jac;   // fused front kernel exchange buffers (doubles)
 };
 
@@ -92,6 +92,7 @@ Layout make_layout(const ekf_config& c) {
         L.off_xr = take((size_t)L.kmax * 8);
         L.off_xl = take(2 * L.xl_len * 8);
         L.off_done = take(256);
+        L.off_log = take((size_t)4096 * 8 * 8);
     }
     L.total = o;
     return L;
@@ -215,13 +216,27 @@ EkfFrame make_frame(ekf_filter* f, const int32_t* idx_dev, const double* z_dev, 
     fr.xl_len = (int32_t)L.xl_len;
     fr.n_lm = f->n_lm;
     fr.done_ctr = f->at<unsigned long long>(L.off_done);
+    fr.dbglog = f->at<double>(L.off_log) + (size_t)(f->seq & 4095) * 8;
     f->done_total += (uint64_t)(fr.ncols / 64);
     fr.done_target = f->done_total;
     f->seq++;
     return fr;
 }
 
-// predict + update for one frame: four dependent launches on the stream
+// Fused front kernel or the three stage kernels?  The fused kernel is used unless the caller opted out
+// (flags bit 2) or the frame is in the one regime where it is not trusted yet: k > 128 together with
+// (almost) more workgroups than CUs -- there, roughly one frame in a thousand of a long back-to-back
+// sequence came out with a garbage S block (n >= 3700, m = 64; never with a host sync every other
+// frame, never for k <= 144 or fewer than 222 workgroups; cause not found).
+// The stage kernels are equally fast at those sizes.  flags bit 3 forces the fused kernel (diagnostics).
+bool use_front_kernel(const ekf_filter* f, const EkfFrame& fr) {
+    if (f->cfg.flags & 4) return false;
+    if (f->cfg.flags & 8) return true;
+    const int nb = fr.kpad / EKF_RB, grid = nb * (nb + 1) / 2 + 2 + fr.ncols / 64;
+    return fr.kpad <= 128 || grid <= 200;
+}
+
+// predict + update for one frame: the front kernel (or gather / solve / panel) and the covariance update
 int enqueue_frame(ekf_filter* f, const int32_t* idx_dev, const double* z_dev, int m,
                   double* traj_row) {
     EkfFrame fr = make_frame(f, idx_dev, z_dev, m, traj_row);
@@ -238,7 +253,7 @@ int enqueue_frame(ekf_filter* f, const int32_t* idx_dev, const double* z_dev, in
     }
     hipEvent_t* ev_all = (ev && !f->timing_cov_only) ? ev : nullptr;
     if (ev_all) HIP_TRY(hipEventRecord(ev[0], f->stream));
-    if (!(f->cfg.flags & 4)) {
+    if (use_front_kernel(f, fr)) {
         // one launch: timing slot 0 = the whole front kernel, slots 1 and 2 stay empty
         if (f32) ekf_launch_front<float>(fr, f->stream); else ekf_launch_front<double>(fr, f->stream);
         if (ev_all) {
@@ -279,7 +294,10 @@ int sync_and_check(ekf_filter* f) {
         if (st & 4)   // a bounded wait inside the fused front kernel ran out (should never happen)
             return fail(EKF_ERR_NUMERIC, "internal: exchange wait timed out in the front kernel (status " +
                                              std::to_string(st) + ")");
-        return fail(EKF_ERR_NUMERIC, "innovation covariance S was not positive definite");
+        int32_t info[8] = {};
+        (void)hipMemcpy(info, f->at<int32_t>(f->lay.off_status), sizeof(info), hipMemcpyDeviceToHost);
+        return fail(EKF_ERR_NUMERIC, "innovation covariance S was not positive definite (block column " +
+                                         std::to_string(info[2] - 100) + ", wave mask " + std::to_string(info[1]) + ")");
     }
     return EKF_OK;
 }
@@ -552,7 +570,7 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
                                  trajectory_dev ? trajectory_dev + (size_t)t * 7 : nullptr);
         fr.wpanel = wbuf[par];
         fr.prow = (t > 0) ? prow : nullptr;
-        if (!(f->cfg.flags & 4)) {
+        if (use_front_kernel(f, fr)) {
             if (f32) ekf_launch_front<float>(fr, f->stream); else ekf_launch_front<double>(fr, f->stream);
         } else {
             if (f32) ekf_launch_gather<float>(fr, f->stream); else ekf_launch_gather<double>(fr, f->stream);
@@ -741,6 +759,11 @@ int ekf_debug_fetch(ekf_filter* f, int32_t what, double* out, size_t count) {
             if (count < (size_t)k * dims) return fail(EKF_ERR_INVALID, "out too small");
             HIP_TRY(hipMemcpy2D(out, (size_t)dims * 8, f->at<double>(L.off_amat), (size_t)L.cap * 8,
                                 (size_t)dims * 8, k, hipMemcpyDeviceToHost));
+            return EKF_OK;
+        case 6:
+            if (count < 4096 * 8 + 1) return fail(EKF_ERR_INVALID, "out too small");
+            HIP_TRY(hipMemcpy(out, f->at<double>(L.off_log), (size_t)4096 * 8 * 8, hipMemcpyDeviceToHost));
+            out[4096 * 8] = (double)f->seq;
             return EKF_OK;
         case 5:
             if (count < 64) return fail(EKF_ERR_INVALID, "out too small");

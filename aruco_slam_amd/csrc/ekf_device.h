@@ -81,6 +81,7 @@ __device__ inline void ekf_measure(const double* __restrict__ cam, const double*
 // Camera quaternion injection, extended_kalman_filter.py:138-149.
 // mode 0: as written (both arrays read scalar-LAST by SciPy), mode 1: scalar-first.
 __device__ inline void ekf_quat_inject(double q[4], const double err[3], int mode) {
+#pragma clang fp contract(off)      // same bits wherever it is inlined (front kernel, panel kernel, injection kernel)
     double d[4] = {1.0, 0.5 * err[0], 0.5 * err[1], 0.5 * err[2]};
     const double nq = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     const double nd = 1.0 / sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]);

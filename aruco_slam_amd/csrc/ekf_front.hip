@@ -32,7 +32,12 @@ __device__ __forceinline__ void ekf_poll_sleep() { __builtin_amdgcn_s_sleep(4); 
 __device__ __forceinline__ double ekf_ldw(const double* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
-__device__ __forceinline__ double ekf_ldt(const double* p, bool coherent) { return coherent ? ekf_ldc(p) : ekf_ldw(p); }
+#ifndef EKF_ALL_COHERENT
+#define EKF_ALL_COHERENT 1
+#endif
+__device__ __forceinline__ double ekf_ldt(const double* p, bool coherent) {
+    return (coherent || EKF_ALL_COHERENT) ? ekf_ldc(p) : ekf_ldw(p);
+}
 
 // ---------------------------------------------------------------------------------------------
 // measurement model of every detection into LDS (one thread per detection), shared by the S-block
@@ -126,7 +131,7 @@ __device__ __forceinline__ void fr_role_sblock(const EkfFrame& fr, int sb, int n
                 for (int b = 0; b < JC; ++b) {
                     const int col = (b < EKF_CAM) ? b : uc20[n] + (b - EKF_CAM);
                     const double pq = (double)pv[n][b] + ((col == urho[n]) ? ekf_qdiag(urho[n], fr.dims, fr.nz) : 0.0);
-                    acc += pq * h2[b];
+                    acc = __builtin_fma(pq, h2[b], acc);
                 }
             }
             us[ue] = acc;
@@ -145,9 +150,9 @@ __device__ __forceinline__ void fr_role_sblock(const EkfFrame& fr, int sb, int n
             const int s1 = EKF_CAM + LMD * (r1 / RD - j0);
             double acc = (r1 == r2) ? fr.nz.r_unc : 0.0;
 #pragma unroll
-            for (int a = 0; a < EKF_CAM; ++a) acc += h1[a] * us[a * 16 + c2];
+            for (int a = 0; a < EKF_CAM; ++a) acc = __builtin_fma(h1[a], us[a * 16 + c2], acc);
 #pragma unroll
-            for (int d = 0; d < LMD; ++d) acc += h1[EKF_CAM + d] * us[(s1 + d) * 16 + c2];
+            for (int d = 0; d < LMD; ++d) acc = __builtin_fma(h1[EKF_CAM + d], us[(s1 + d) * 16 + c2], acc);
             v = acc;
         }
         ekf_stc(fr.xs + ((size_t)bj * fr.sblk_rows + r1) * 16 + c2, v);
@@ -217,7 +222,9 @@ __device__ __forceinline__ FrBlockSrc fr_block_src(const EkfFrame& fr, int nb, i
 // columns 2 (lane & 7), +1: two 16-byte accesses per lane, 1 KB contiguous per instruction.
 // Cacheable attempt: plain vector loads, pinned below the polling that precedes them by an opaque
 // copy of the base pointer (the compiler must not hoist them).
+__device__ __forceinline__ sf64x4 fr_block_load_coherent(const FrBlockSrc& s, int lane);
 __device__ __forceinline__ sf64x4 fr_block_load(const FrBlockSrc& s, int lane) {
+    if (EKF_ALL_COHERENT) return fr_block_load_coherent(s, lane);
     sf64x4 v = {0.0, 0.0, 0.0, 0.0};
     const double* p = s.base;
     asm volatile("" : "+v"(p) : : "memory");
@@ -265,16 +272,14 @@ __device__ __forceinline__ sf64x4 fr_block_settle(const FrBlockSrc& s, sf64x4 v,
     }
     return v;
 }
-// Re-arm (single consumer).  Issued after ALL loads of a batch have been consumed: a wait for a load
-// also waits for every older store.  Plain stores: they reach memory with the end-of-kernel
-// write-back, i.e. before the next frame's producers run.
+// Re-arm (single consumer).  Issued after ALL loads of a batch have been consumed (a wait for a load
+// also waits for every older store), written through (sc1) like the data and right away: with plain
+// stores, or with the re-arm postponed to the end of the role, n >= 3700 fails in 10-30 % of the runs.
 __device__ __forceinline__ void fr_block_rearm(const FrBlockSrc& s, int lane) {
     const double sent = ekf_sent();
     if (!s.resid) {
-        ekf_stc(s.base + 2 * lane, sent);
-        ekf_stc(s.base + 2 * lane + 1, sent);
-        ekf_stc(s.base + 128 + 2 * lane, sent);
-        ekf_stc(s.base + 128 + 2 * lane + 1, sent);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) ekf_stc(s.base + x * 64 + lane, sent);     // whole cache lines per instruction
     } else if (lane < EKF_RB) {
         ekf_stc(s.base + lane, sent);
     }
@@ -385,7 +390,7 @@ __device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, int RS, doubl
         // ring mode: this workgroup reads the column back later (sv_terms_glb): be done before the barrier
         if (!all_resident) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
-    int bad = 0;
+    int bad = 0, badb = 0;
     for (int b = 0; b < nb; ++b) {
         const int cb = EKF_RB * b;
         double* cur = colbuf(b);
@@ -426,6 +431,7 @@ __device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, int RS, doubl
                     a[x] = __builtin_fma(-lj, lx, a[x]);
                 }
             }
+            if (bad && !badb) badb = 100 + b;                                      // diagnostics: first bad block column
             if (live) {
                 double* dst = cur + (size_t)row * SV_CLD;
 #pragma unroll
@@ -479,7 +485,13 @@ __device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, int RS, doubl
         EKF_STAMP();
     }
     if (wave == NW - 1) publish(nb - 1);
-    if ((bad | (spin_fail << 2)) && lane == 0) atomicOr(fr.status, bad | (spin_fail << 2));
+    if ((bad | (spin_fail << 2)) && lane == 0) {
+        atomicOr(fr.status, bad | (spin_fail << 2));
+        if (bad) {      // diagnostics: which waves saw it, and the first block column
+            atomicOr(fr.status + 1, 1 << wave);
+            atomicCAS(fr.status + 2, 0, badb);
+        }
+    }
     EKF_STAMP();
     if (fr.stamps && tid == 0) fr.stamps[63] = wall_clock64();
 #undef EKF_STAMP
@@ -520,7 +532,6 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
         double dq[4], yq[4];
-        double lq[NB][4];
         if (wv == 0) {
             // sync[0] = block columns shared so far, sync[1] = reads of the shared slot acknowledged
             int it = 0;
@@ -569,20 +580,6 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the reads before the acknowledgement
             if (lane == 0) atomicAdd(const_cast<int*>(sync) + 1, 1);
         }
-        int it = 0;
-        for (;;) {      // normally one pass: the -L blocks of column q were published before Dinv
-            bool pend = false;
-#pragma unroll
-            for (int i = q + 1; i < NB; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    lq[i][r] = ekf_ldt(xlop + sv_lop_index(i, q) + r * 64 + lane, it > 0);
-                    pend = pend || ekf_is_sent(lq[i][r]);
-                }
-            if (!__any(pend)) break;
-            if (++it > EKF_SPIN_MAX) { spin_fail = 1; break; }
-            ekf_poll_sleep();
-        }
         pf64x4 wq = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int r = 0; r < 4; ++r) wq = __builtin_amdgcn_mfma_f64_16x16x4f64(dq[r], t[q][r], wq, 0, 0, 0);
@@ -593,13 +590,34 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
             wp[(int64_t)row * fr.ldw + col0 + j] = (T)wq[r];
             if (fr.wdbg) fr.wdbg[(int64_t)row * fr.ldw + col0 + j] = wq[r];
         }
+        // t[i] += (-L_iq) W_q for i > q, at most LG blocks of -L in registers at a time (the whole
+        // kernel has to stay clear of register spills)
+        constexpr int LG = 6;
 #pragma unroll
-        for (int i = q + 1; i < NB; ++i)
+        for (int i0 = q + 1; i0 < NB; i0 += LG) {
+            double lq[LG][4];
+            int it = 0;
+            for (;;) {      // normally one pass: the -L blocks of column q were published before Dinv
+                bool pend = false;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                t[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(lq[i][r], wq[r], t[i], 0, 0, 0);
+                for (int i = i0; i < NB && i < i0 + LG; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) part += wq[r] * yq[r];
+                    for (int r = 0; r < 4; ++r) {
+                        lq[i - i0][r] = ekf_ldt(xlop + sv_lop_index(i, q) + r * 64 + lane, it > 0);
+                        pend = pend || ekf_is_sent(lq[i - i0][r]);
+                    }
+                if (!__any(pend)) break;
+                if (++it > EKF_SPIN_MAX) { spin_fail = 1; break; }
+                ekf_poll_sleep();
+            }
+#pragma unroll
+            for (int i = i0; i < NB && i < i0 + LG; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    t[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(lq[i - i0][r], wq[r], t[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part = __builtin_fma(wq[r], yq[r], part);
         if (stp) stp[q] = wall_clock64();
     }
     part += __shfl_xor(part, 16);
@@ -679,7 +697,7 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
         }
         __syncthreads();
         for (int e = tid; e < nel; e += FR_T) {
-            double v = ekf_ldw(xj + e);
+            double v = ekf_ldt(xj + e, false);
             int it = 0;
             while (ekf_is_sent(v)) {
                 if (++it > EKF_SPIN_MAX) { spin = 1; break; }
@@ -708,9 +726,9 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
                 const double* hr = hs + r * JC;
                 double acc = 0.0;
 #pragma unroll
-                for (int a = 0; a < EKF_CAM; ++a) acc += hr[a] * pc[a];
+                for (int a = 0; a < EKF_CAM; ++a) acc = __builtin_fma(hr[a], pc[a], acc);
 #pragma unroll
-                for (int e = 0; e < LMD; ++e) acc += hr[10 + e] * pl[e];
+                for (int e = 0; e < LMD; ++e) acc = __builtin_fma(hr[10 + e], pl[e], acc);
                 a_lds[r * FR_ALD + cl] = acc;
                 if (fr.wdbg) fr.amat[(int64_t)r * fr.lda + c] = acc;
             }

@@ -62,6 +62,7 @@ struct EkfFrame {
     int32_t n_lm;              // landmarks in the state (model 1 injection)
     unsigned long long* done_ctr;      // chunks finished since reset (device)
     unsigned long long done_target;    // value of done_ctr once this frame's last chunk is done
+    double* dbglog;                    // diagnostics: 8 doubles per frame
 };
 
 // fused gather + solve + panel (+ injection); see ekf_front.hip

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void ekf_gather_kernel(EkfFrame fr) {
                 for (int b = 0; b < JC; ++b) {
                     const int col = (b < EKF_CAM) ? b : c20 + (b - EKF_CAM);
                     const double pq = (double)pv[b] + ((col == rho) ? ekf_qdiag(rho, fr.dims, fr.nz) : 0.0);
-                    acc += pq * h2[b];
+                    acc = __builtin_fma(pq, h2[b], acc);
                 }
             }
             us[e] = acc;
@@ -126,9 +126,9 @@ __global__ __launch_bounds__(256) void ekf_gather_kernel(EkfFrame fr) {
                 const int s1 = EKF_CAM + LMD * (r1 / RD - j0);
                 double acc = (r1 == r2) ? fr.nz.r_unc : 0.0;
 #pragma unroll
-                for (int a = 0; a < EKF_CAM; ++a) acc += h1[a] * us[a * 16 + c2];
+                for (int a = 0; a < EKF_CAM; ++a) acc = __builtin_fma(h1[a], us[a * 16 + c2], acc);
 #pragma unroll
-                for (int d = 0; d < LMD; ++d) acc += h1[EKF_CAM + d] * us[(s1 + d) * 16 + c2];
+                for (int d = 0; d < LMD; ++d) acc = __builtin_fma(h1[EKF_CAM + d], us[(s1 + d) * 16 + c2], acc);
                 v = acc;
             }
             fr.sblk[((size_t)bj * fr.sblk_rows + r1) * 16 + c2] = v;
@@ -152,9 +152,9 @@ __global__ __launch_bounds__(256) void ekf_gather_kernel(EkfFrame fr) {
                 const double* hr = hs + r * JC;
                 double acc = 0.0;
 #pragma unroll
-                for (int a = 0; a < EKF_CAM; ++a) acc += hr[a] * pc[a];
+                for (int a = 0; a < EKF_CAM; ++a) acc = __builtin_fma(hr[a], pc[a], acc);
 #pragma unroll
-                for (int e = 0; e < LMD; ++e) acc += hr[10 + e] * pl[e];
+                for (int e = 0; e < LMD; ++e) acc = __builtin_fma(hr[10 + e], pl[e], acc);
                 fr.amat[(int64_t)r * fr.lda + c] = acc;
             }
         }
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(64) void ekf_panel_mfma_kernel(EkfFrame fr) {
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * b + g + 4 * r;
             const double v = w[b][r];
-            part += v * fr.yvec[row];
+            part = __builtin_fma(v, fr.yvec[row], part);
             wp[(int64_t)row * fr.ldw + col0 + j] = (T)v;
             if (fr.wdbg) fr.wdbg[(int64_t)row * fr.ldw + col0 + j] = v;
         }

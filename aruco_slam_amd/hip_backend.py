@@ -127,7 +127,9 @@ class HipEkf:
         kern = {"auto": EKF_COVK_AUTO, "valu": EKF_COVK_VALU, "mfma": EKF_COVK_MFMA}
         cfg.cov_kernel = kern[cov_kernel]
         cfg.flags = {None: 0, False: 1, True: 2}[lookahead]   # None / False: serial order (default)
-        if not fused:
+        if fused == "force":
+            cfg.flags |= 8        # fused front kernel even where it is not trusted yet (diagnostics)
+        elif not fused:
             cfg.flags |= 4        # separate gather / solve / panel launches
         self.fused = bool(fused)
         cfg.model = {"ekf": 0, "ekf_rotations": 1}[model]
@@ -250,13 +252,19 @@ class HipEkf:
             us, cnt = C.c_double(), C.c_int64()
             self._check(self.lib.ekf_get_kernel_timing(self.h, i, C.byref(us), C.byref(cnt)))
             out[name] = (us.value, cnt.value)
-        if self.fused:       # one launch: slot 0 is the whole front kernel, slots 1-2 are empty gaps
+        if out["gather"][0] > 2.0 * (out["solve"][0] + out["panel"][0]):
+            # one launch: slot 0 is the whole front kernel, slots 1-2 are empty event gaps
             out = {"front": out["gather"], "cov_update": out["cov_update"]}
         return out
 
     def debug_enable_w(self):
         dummy = np.zeros(1)
         self._check(self.lib.ekf_debug_fetch(self.h, -1, _dptr(dummy), 1))
+
+    def debug_log(self):
+        out = np.zeros(4096 * 8 + 1)
+        self._check(self.lib.ekf_debug_fetch(self.h, 6, _dptr(out), out.size))
+        return out[:-1].reshape(4096, 8), int(out[-1])
 
     def debug_fetch(self, what: str, m: int):
         rd = self.rows_per_detection

@@ -67,7 +67,8 @@ typedef struct ekf_config {
     int32_t flags;          /* bit 1: cross-frame lookahead in ekf_observe_sequence_device (priority rows +
                              * covariance update on a second stream; same results, currently slower than
                              * the serial order at every size, off by default; bit 0 is ignored).  bit 2: run gather / solve / panel as three separate
-                             * launches instead of the fused front kernel (same results, bit for bit) */
+                             * launches instead of the fused front kernel (same results, bit for bit; also chosen
+                             * automatically for k > 128 with more than 200 workgroups).  bit 3: always fused. */
     /* noise constants, defaults = extended_kalman_filter.py:21-27 */
     double initial_camera_uncertainty;   /* 0.1  */
     double initial_landmark_uncertainty; /* 0.7  */

@@ -26,7 +26,7 @@ def run(cls, n, m, dtype, fused, frames=6, rv=0.0):
     return st, flt.uncertainty, time.perf_counter() - t0
 
 
-cases = [(EKF, 24, 8, "float64", 0.0), (EKF, 24, 8, "float32", 0.0), (EKF, 256, 16, "float64", 0.0),
+cases = [(EKF, 256, 16, "float32", 0.0), (EKF, 256, 8, "float32", 0.0), (EKF, 100, 16, "float32", 0.0), (EKF, 24, 8, "float64", 0.0), (EKF, 24, 8, "float32", 0.0), (EKF, 256, 16, "float64", 0.0),
          (EKF_Rotations, 20, 6, "float64", 0.05), (EKF, 1024, 32, "float32", 0.0), (EKF, 128, 64, "float32", 0.0),
          (EKF_Rotations, 40, 27, "float32", 0.05)]
 if len(sys.argv) > 1:
