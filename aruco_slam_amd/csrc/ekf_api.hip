@@ -44,7 +44,7 @@ struct Layout {
     size_t off_jac, off_resid, off_y, off_lmcol, off_amat, off_sblk, off_lmat, off_dinv, off_lop, off_dop, off_wpanel, off_wpanel2, off_prow, off_wdbg,
         off_idx, off_z, off_status, off_stamps, off_dx, off_diag, off_xyz, off_unc,
         off_xs, off_xr, off_xl, off_done, off_log, total;
-    size_t xs_len, xl_len, xl_dop, xl_y, xl_jac;   // fused front kernel exchange buffers (doubles)
+    size_t xs_len, xl_len, xl_dop, xl_y, xl_jac, xl_tag;   // fused front kernel exchange buffers (doubles)
 };
 
 Layout make_layout(const ekf_config& c) {
@@ -87,7 +87,8 @@ Layout make_layout(const ekf_config& c) {
         L.xl_dop = nb * (nb - 1) / 2 * 256 + 64;
         L.xl_y = L.xl_dop + nb * 256;
         L.xl_jac = L.xl_y + L.kmax;
-        L.xl_len = L.xl_jac + (size_t)L.kmax * EKF_JLD;
+        L.xl_tag = L.xl_jac + (size_t)L.kmax * EKF_JLD;
+        L.xl_len = L.xl_tag + 32;
         L.off_xs = take(L.xs_len * 8);
         L.off_xr = take((size_t)L.kmax * 8);
         L.off_xl = take(2 * L.xl_len * 8);
@@ -213,6 +214,8 @@ EkfFrame make_frame(ekf_filter* f, const int32_t* idx_dev, const double* z_dev, 
     fr.xl_dop = (int32_t)L.xl_dop;
     fr.xl_y = (int32_t)L.xl_y;
     fr.xl_jac = (int32_t)L.xl_jac;
+    fr.xl_tag = (int32_t)L.xl_tag;
+    fr.seqno = (double)(f->seq + 1);
     fr.xl_len = (int32_t)L.xl_len;
     fr.n_lm = f->n_lm;
     fr.done_ctr = f->at<unsigned long long>(L.off_done);
@@ -291,6 +294,9 @@ int sync_and_check(ekf_filter* f) {
     HIP_TRY(hipMemcpy(&st, f->at<int32_t>(f->lay.off_status), sizeof(st), hipMemcpyDeviceToHost));
     static const bool ignore = getenv("EKF_IGNORE_NUMERIC") != nullptr;   // timing ablations only
     if (st != 0 && !ignore) {
+        if (st & (16 | 32))   // diagnostics: a chunk accepted exchange data that carries another frame's tag
+            return fail(EKF_ERR_NUMERIC, "internal: stale exchange data accepted in the front kernel (status " +
+                                             std::to_string(st) + ")");
         if (st & 4)   // a bounded wait inside the fused front kernel ran out (should never happen)
             return fail(EKF_ERR_NUMERIC, "internal: exchange wait timed out in the front kernel (status " +
                                              std::to_string(st) + ")");

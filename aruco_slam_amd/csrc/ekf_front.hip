@@ -191,6 +191,7 @@ __device__ __forceinline__ void fr_role_measure(const EkfFrame& fr, double* sm) 
     const int nel = fr.k * JC;
     for (int e = tid; e < nel; e += FR_T) ekf_stc(xj + e, hs[e]);
     for (int e = tid; e < fr.kpad; e += FR_T) ekf_stc(fr.xr + e, rsd[e]);
+    if (tid == 0) ekf_stc(fr.xl + fr.xl_tag, fr.seqno);
     if (fr.stamps && tid == 0) fr.stamps[55] = wall_clock64();
 }
 
@@ -387,6 +388,7 @@ __device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, int RS, doubl
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             ekf_stc(xdop + (size_t)(pb * 4 + r) * 64 + lane, dv[r]);
+        if (lane == 0) ekf_stc(fr.xl + fr.xl_tag + 1 + pb, fr.seqno);
         // ring mode: this workgroup reads the column back later (sv_terms_glb): be done before the barrier
         if (!all_resident) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
@@ -580,6 +582,10 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the reads before the acknowledgement
             if (lane == 0) atomicAdd(const_cast<int*>(sync) + 1, 1);
         }
+        if (wv == 0 && lane == 0) {
+            const double tag = ekf_ldc(fr.xl + fr.xl_tag + 1 + q);
+            if (!ekf_is_sent(tag) && tag != fr.seqno) atomicOr(fr.status, 32);
+        }
         pf64x4 wq = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int r = 0; r < 4; ++r) wq = __builtin_amdgcn_mfma_f64_16x16x4f64(dq[r], t[q][r], wq, 0, 0, 0);
@@ -707,6 +713,10 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
             hs[e] = v;
         }
         if (spin) atomicOr(fr.status, 4);
+        if (tid == 0) {
+            const double tag = ekf_ldc(fr.xl + fr.xl_tag);
+            if (!ekf_is_sent(tag) && tag != fr.seqno) atomicOr(fr.status, 16);
+        }
     }
     __syncthreads();
     double pc[EKF_CAM];

@@ -63,6 +63,8 @@ struct EkfFrame {
     unsigned long long* done_ctr;      // chunks finished since reset (device)
     unsigned long long done_target;    // value of done_ctr once this frame's last chunk is done
     double* dbglog;                    // diagnostics: 8 doubles per frame
+    int32_t xl_tag;                    // diagnostics: frame tags inside xl ([0] Jacobian, [1 + q] block column q)
+    double seqno;                      // this frame's tag
 };
 
 // fused gather + solve + panel (+ injection); see ekf_front.hip
