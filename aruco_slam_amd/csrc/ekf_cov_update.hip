@@ -288,6 +288,58 @@ __global__ __launch_bounds__(256) void ekf_cov_update_mfma_f64(EkfFrame fr, int 
 }
 
 // --------------------------------------------------------------------------
+// MFMA f64, small problems: the same 32x32 tiles, but ONE WORKGROUP per tile and one 16x16 sub-tile
+// per wave (same MFMA sequence per sub-tile: bitwise the results of the kernel above).  With a few
+// hundred tiles the one-wave-per-tile kernel leaves most of the 1024 SIMDs idle and every wave runs
+// 4x the serial work; here n=256 (325 tiles) becomes 1300 waves.
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ekf_cov_update_mfma_f64_split(EkfFrame fr, int nitems) {
+    __shared__ double tr[32][33];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = lane & 15, g = lane >> 4;
+    const int ri = wave >> 1, ci = wave & 1;
+    int I, J;
+    ekf_tri_decode(blockIdx.x, I, J);
+    const int i0 = 32 * I, j0 = 32 * J;
+    const double* __restrict__ wp = static_cast<const double*>(fr.wpanel);
+    double* __restrict__ P = static_cast<double*>(fr.cov);
+    const int64_t ld = fr.ld, ldw = fr.ldw;
+    double pt[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pt[r] = P[(int64_t)(i0 + 16 * ri + g + 4 * r) * ld + j0 + 16 * ci + c];
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+    const double* wa = wp + (int64_t)g * ldw + i0 + 16 * ri + c;
+    const double* wb = wp + (int64_t)g * ldw + j0 + 16 * ci + c;
+    const int steps = fr.kpad >> 2;                   // multiple of 4
+    for (int ks = 0; ks < steps; ks += 4) {
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t off = (int64_t)(4 * (ks + u)) * ldw;
+            a[u] = wa[off];
+            b[u] = wb[off];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[u], b[u], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int rl = 16 * ri + g + 4 * r, cl = 16 * ci + c;
+        double v = pt[r];
+        if (I == J && rl == cl) v += ekf_qdiag(i0 + rl, fr.dims, fr.nz);
+        v += acc[r];
+        P[(int64_t)(i0 + rl) * ld + j0 + cl] = v;
+        if (I != J) tr[rl][cl] = v;
+    }
+    if (I != J) {
+        __syncthreads();
+        const int l31 = threadIdx.x & 31;
+        for (int cc = threadIdx.x >> 5; cc < 32; cc += 8)          // column cc of D = row of D^T
+            P[(int64_t)(j0 + cc) * ld + i0 + l31] = tr[l31][cc];
+    }
+}
+
+// --------------------------------------------------------------------------
 // Priority rows (cross-frame lookahead): the rows of the UPDATED covariance that the next frame's
 // gather reads -- camera rows 0..9 and the 3 rows of every next-frame detection -- computed
 // ahead of the big kernel into a side buffer, with exactly the per-element arithmetic of the
@@ -362,6 +414,9 @@ void ekf_launch_cov_update<double>(const EkfFrame& fr, int variant, hipStream_t 
                            dim3(256), 0, s, fr);
     } else {
         const int items = ekf_tri_items(fr);
-        hipLaunchKernelGGL(ekf_cov_update_mfma_f64, dim3((items + 3) / 4), dim3(256), 0, s, fr, items);
+        if (items <= 2048)      // small problem: one workgroup per tile, one 16x16 sub-tile per wave
+            hipLaunchKernelGGL(ekf_cov_update_mfma_f64_split, dim3(items), dim3(256), 0, s, fr, items);
+        else
+            hipLaunchKernelGGL(ekf_cov_update_mfma_f64, dim3((items + 3) / 4), dim3(256), 0, s, fr, items);
     }
 }

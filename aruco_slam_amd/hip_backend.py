@@ -131,7 +131,8 @@ class HipEkf:
             cfg.flags |= 8        # fused front kernel even where it is not trusted yet (diagnostics)
         elif not fused:
             cfg.flags |= 4        # separate gather / solve / panel launches
-        self.fused = bool(fused)
+        self.fused = fused if fused == "force" else bool(fused)
+        self._last_m = 1
         cfg.model = {"ekf": 0, "ekf_rotations": 1}[model]
         self.lm_dims, self.rows_per_detection = (10, 7) if cfg.model == 1 else (3, 3)
         for key, val in (noise or {}).items():
@@ -200,6 +201,7 @@ class HipEkf:
         idx = np.ascontiguousarray(lm_index, dtype=np.int32)
         z = np.ascontiguousarray(z, dtype=np.float64).reshape(-1, self.rows_per_detection)
         assert idx.shape[0] == z.shape[0]
+        self._last_m = idx.shape[0]
         self._check(self.lib.ekf_observe(self.h, idx.ctypes.data_as(C.POINTER(C.c_int32)), _dptr(z),
                                          idx.shape[0]))
 
@@ -209,6 +211,7 @@ class HipEkf:
         frames, m = idx_t.shape
         assert idx_t.is_cuda and z_t.is_cuda and idx_t.is_contiguous() and z_t.is_contiguous()
         assert tuple(z_t.shape) == (frames, m, self.rows_per_detection)
+        self._last_m = m
         self._check(self.lib.ekf_observe_sequence_device(
             self.h, idx_t.data_ptr(), z_t.data_ptr(), m, frames,
             traj_t.data_ptr() if traj_t is not None else None))
@@ -252,10 +255,21 @@ class HipEkf:
             us, cnt = C.c_double(), C.c_int64()
             self._check(self.lib.ekf_get_kernel_timing(self.h, i, C.byref(us), C.byref(cnt)))
             out[name] = (us.value, cnt.value)
-        if out["gather"][0] > 2.0 * (out["solve"][0] + out["panel"][0]):
+        if self.front_kernel_used(self._last_m):
             # one launch: slot 0 is the whole front kernel, slots 1-2 are empty event gaps
             out = {"front": out["gather"], "cov_update": out["cov_update"]}
         return out
+
+    def front_kernel_used(self, m: int) -> bool:
+        """Mirror of use_front_kernel() in csrc/ekf_api.hip: fused front kernel or the three stage kernels?"""
+        if self.fused == "force":
+            return True
+        if not self.fused:
+            return False
+        kpad = -(-self.rows_per_detection * max(int(m), 1) // 16) * 16
+        nb = kpad // 16
+        grid = nb * (nb + 1) // 2 + 2 + (-(-self.dims // 128) * 128) // 64
+        return kpad <= 128 or grid <= 200
 
     def debug_enable_w(self):
         dummy = np.zeros(1)
