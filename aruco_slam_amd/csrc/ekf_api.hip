@@ -216,6 +216,8 @@ EkfFrame make_frame(ekf_filter* f, const int32_t* idx_dev, const double* z_dev, 
     fr.xl_jac = (int32_t)L.xl_jac;
     fr.xl_tag = (int32_t)L.xl_tag;
     fr.seqno = (double)(f->seq + 1);
+    static const int opt = getenv("EKF_OPT") ? atoi(getenv("EKF_OPT")) : 0;
+    fr.opt = opt;
     fr.xl_len = (int32_t)L.xl_len;
     fr.n_lm = f->n_lm;
     fr.done_ctr = f->at<unsigned long long>(L.off_done);

@@ -27,17 +27,9 @@
 typedef double pf64x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void ekf_poll_sleep() { __builtin_amdgcn_s_sleep(4); }
-// cacheable load (may hit in L1 / this XCD's L2) that the compiler neither hoists nor merges; used
-// for the first attempt once a poller has seen the producer's data, retries go through ekf_ldc
-__device__ __forceinline__ double ekf_ldw(const double* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-}
-#ifndef EKF_ALL_COHERENT
-#define EKF_ALL_COHERENT 1
-#endif
-__device__ __forceinline__ double ekf_ldt(const double* p, bool coherent) {
-    return (coherent || EKF_ALL_COHERENT) ? ekf_ldc(p) : ekf_ldw(p);
-}
+// every exchange read is a coherent load (`coherent` kept for readability at the call sites: first
+// attempt vs retry)
+__device__ __forceinline__ double ekf_ldt(const double* p, bool /*coherent*/) { return ekf_ldc(p); }
 
 // ---------------------------------------------------------------------------------------------
 // measurement model of every detection into LDS (one thread per detection), shared by the S-block
@@ -206,7 +198,6 @@ __device__ __forceinline__ void fr_role_measure(const EkfFrame& fr, double* sm) 
 // launch has touched those lines before; whatever has not landed yet still reads as a sentinel and
 // is re-read coherently).
 struct FrBlockSrc { double* base; const double* w; bool resid; };
-typedef double fr_d2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ FrBlockSrc fr_block_src(const EkfFrame& fr, int nb, int i, int tc, int lane) {
     FrBlockSrc s;
     s.resid = i >= nb;
@@ -220,24 +211,34 @@ __device__ __forceinline__ FrBlockSrc fr_block_src(const EkfFrame& fr, int nb, i
     return s;
 }
 // Lane <-> word mapping of a 2 KB block: words 128 x + 2 lane, +1 (x = 0, 1), i.e. row 8x + (lane >> 3),
-// columns 2 (lane & 7), +1: two 16-byte accesses per lane, 1 KB contiguous per instruction.
-// Cacheable attempt: plain vector loads, pinned below the polling that precedes them by an opaque
-// copy of the base pointer (the compiler must not hoist them).
-__device__ __forceinline__ sf64x4 fr_block_load_coherent(const FrBlockSrc& s, int lane);
-__device__ __forceinline__ sf64x4 fr_block_load(const FrBlockSrc& s, int lane) {
-    if (EKF_ALL_COHERENT) return fr_block_load_coherent(s, lane);
-    sf64x4 v = {0.0, 0.0, 0.0, 0.0};
-    const double* p = s.base;
-    asm volatile("" : "+v"(p) : : "memory");
+// columns 2 (lane & 7), +1.  All exchange reads are coherent (sc1) loads; their cost is per instruction
+// (~400 cycles each when eight waves fetch at once), so the bulk uses 16-byte loads, written as inline asm
+// (the atomic builtins stop at 8 bytes): issue with fr_block_issue, then ONE fr_block_arrive for the
+// whole batch before the values are used.  Retries use the 8-byte builtin.
+typedef double fr_d2 __attribute__((ext_vector_type(2)));
+struct FrBlockRaw { fr_d2 a, b; };
+__device__ __forceinline__ void fr_block_issue(FrBlockRaw& r, const FrBlockSrc& s, int lane) {
+    r.a = fr_d2{0.0, 0.0};
+    r.b = fr_d2{0.0, 0.0};
     if (!s.resid) {
-        const fr_d2 a = *reinterpret_cast<const fr_d2*>(p + 2 * lane);
-        const fr_d2 b = *reinterpret_cast<const fr_d2*>(p + 128 + 2 * lane);
-        v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
+        const double* p0 = s.base + 2 * lane;
+        const double* p1 = s.base + 128 + 2 * lane;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r.a) : "v"(p0) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r.b) : "v"(p1) : "memory");
     } else if (lane < EKF_RB) {
-        v[0] = p[lane];
+        const double* p0 = s.base + lane;
+        double v;
+        asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v) : "v"(p0) : "memory");
+        r.a[0] = v;
     }
-    return v;
 }
+template <int N>
+__device__ __forceinline__ void fr_block_arrive(FrBlockRaw (&r)[N]) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < N; ++j) asm volatile("" : "+v"(r[j].a), "+v"(r[j].b));       // uses stay below the wait
+}
+__device__ __forceinline__ sf64x4 fr_block_value(const FrBlockRaw& r) { return sf64x4{r.a[0], r.a[1], r.b[0], r.b[1]}; }
 __device__ __forceinline__ sf64x4 fr_block_load_coherent(const FrBlockSrc& s, int lane) {
     sf64x4 v = {0.0, 0.0, 0.0, 0.0};
     if (!s.resid) {
@@ -249,6 +250,12 @@ __device__ __forceinline__ sf64x4 fr_block_load_coherent(const FrBlockSrc& s, in
         v[0] = ekf_ldc(s.base + lane);
     }
     return v;
+}
+__device__ __forceinline__ sf64x4 fr_block_load(const FrBlockSrc& s, int lane) {      // single block (ring mode)
+    FrBlockRaw r[1];
+    fr_block_issue(r[0], s, lane);
+    fr_block_arrive(r);
+    return fr_block_value(r[0]);
 }
 __device__ __forceinline__ bool fr_block_pending(const sf64x4& v) {
     const bool p = ekf_is_sent(v[0]) || ekf_is_sent(v[1]) || ekf_is_sent(v[2]) || ekf_is_sent(v[3]);
@@ -315,11 +322,12 @@ __device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, int RS, doubl
 #define EKF_STAMP() do { if (fr.stamps && tid == 0) fr.stamps[nstamp] = clock64(); ++nstamp; } while (0)
     if (fr.stamps && tid == 0) fr.stamps[62] = wall_clock64();
     EKF_STAMP();
-    constexpr int PB = 6;
-    // block columns brought into LDS before the first pivot chain: all of them when they all stay
-    // resident (the free waves have no slack for memory round trips during the chains), else 0 and 1
-    // (column c >= 2 then arrives during iteration c - 2)
-    const int ncol0 = all_resident ? nb : (nb > 1 ? 2 : 1);
+    constexpr int PB = 4;       // (small on purpose: this code runs once per launch, i.e. from a cold instruction cache)
+    // block columns brought into LDS before the first pivot chain: only column 0 when all columns stay
+    // resident (the others arrive during iteration 0, whose free waves have nothing else to do; later
+    // iterations have no slack for memory round trips), else 0 and 1 (column c >= 2 then arrives
+    // during iteration c - 2)
+    const int ncol0 = all_resident ? 1 : (nb > 1 ? 2 : 1);
     int ntot = 0;
     for (int tc = 0; tc < ncol0; ++tc) ntot += nb - tc + 1;
     sf64x4 pv[PB];
@@ -348,9 +356,15 @@ __device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, int RS, doubl
             ekf_poll_sleep();
         }
     }
+    {
+        FrBlockRaw raw[PB];
 #pragma unroll
-    for (int j = 0; j < PB; ++j)
-        if (pi[j] >= 0) pv[j] = fr_block_load(ps[j], lane);
+        for (int j = 0; j < PB; ++j)
+            if (pi[j] >= 0) fr_block_issue(raw[j], ps[j], lane);
+        fr_block_arrive(raw);
+#pragma unroll
+        for (int j = 0; j < PB; ++j) pv[j] = fr_block_value(raw[j]);
+    }
 #pragma unroll
     for (int j = 0; j < PB; ++j)
         if (pi[j] >= 0) {
@@ -452,6 +466,44 @@ __device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, int RS, doubl
             const bool pubonly = NW - (nrw + 2) >= 3;           // wave NW-1 does nothing but publish
             const int fw = wave - (nrw + 2), nfw = NW - (nrw + 2) - (pubonly ? 1 : 0);
             if (b > 0 && wave == NW - 1) publish(b - 1);       // off the pivot chain's critical path
+            if (all_resident && b == 0 && nb > 1) {
+                // every remaining block column of S, by all non-pivot waves: they were written together
+                // with block column 0, so no polling (a straggler still reads as a sentinel -> retry path)
+                const int fw0 = wave - (nrw + 2), nfw0 = NW - (nrw + 2);
+                int ntot2 = 0;
+                for (int tc = 1; tc < nb; ++tc) ntot2 += nb - tc + 1;
+                for (int base = fw0; base < ntot2; base += nfw0 * PB) {
+                    sf64x4 v2[PB];
+                    FrBlockSrc s2[PB];
+                    int i2[PB], t2[PB];
+#pragma unroll
+                    for (int j = 0; j < PB; ++j) {
+                        int u = base + nfw0 * j, tc = 1;
+                        const bool has = u < ntot2;
+                        u = has ? u : 0;
+                        while (u >= nb - tc + 1) { u -= nb - tc + 1; ++tc; }
+                        i2[j] = has ? tc + u : -1;
+                        t2[j] = tc;
+                        s2[j] = fr_block_src(fr, nb, tc + u, tc, lane);
+                    }
+                    {
+                        FrBlockRaw raw[PB];
+#pragma unroll
+                        for (int j = 0; j < PB; ++j)
+                            if (i2[j] >= 0) fr_block_issue(raw[j], s2[j], lane);
+                        fr_block_arrive(raw);
+#pragma unroll
+                        for (int j = 0; j < PB; ++j) v2[j] = fr_block_value(raw[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < PB; ++j)
+                        if (i2[j] >= 0)
+                            fr_block_put(fr_block_settle(s2[j], v2[j], lane, spin_fail), colbuf(t2[j]), kp, nb, i2[j], lane);
+#pragma unroll
+                    for (int j = 0; j < PB; ++j)
+                        if (i2[j] >= 0) fr_block_rearm(s2[j], lane);
+                }
+            }
             if (pubonly && wave == NW - 1) {
                 // nothing else
             } else {

@@ -65,6 +65,7 @@ struct EkfFrame {
     double* dbglog;                    // diagnostics: 8 doubles per frame
     int32_t xl_tag;                    // diagnostics: frame tags inside xl ([0] Jacobian, [1 + q] block column q)
     double seqno;                      // this frame's tag
+    int32_t opt;                       // experiment switches (diagnostics)
 };
 
 // fused gather + solve + panel (+ injection); see ekf_front.hip
