@@ -43,7 +43,7 @@ struct Layout {
     size_t elem;      // sizeof(cov element)
     size_t off_jac, off_resid, off_y, off_lmcol, off_amat, off_sblk, off_lmat, off_dinv, off_lop, off_dop, off_wpanel, off_wpanel2, off_prow, off_wdbg,
         off_idx, off_z, off_status, off_stamps, off_dx, off_diag, off_xyz, off_unc,
-        off_xs, off_xr, off_xl, off_done, off_log, total;
+        off_xs, off_xr, off_xl, off_done, total;
     size_t xs_len, xl_len, xl_dop, xl_y, xl_jac, xl_tag;   // fused front kernel exchange buffers (doubles)
 };
 
@@ -93,7 +93,6 @@ Layout make_layout(const ekf_config& c) {
         L.off_xr = take((size_t)L.kmax * 8);
         L.off_xl = take(2 * L.xl_len * 8);
         L.off_done = take(256);
-        L.off_log = take((size_t)4096 * 8 * 8);
     }
     L.total = o;
     return L;
@@ -216,12 +215,9 @@ EkfFrame make_frame(ekf_filter* f, const int32_t* idx_dev, const double* z_dev, 
     fr.xl_jac = (int32_t)L.xl_jac;
     fr.xl_tag = (int32_t)L.xl_tag;
     fr.seqno = (double)(f->seq + 1);
-    static const int opt = getenv("EKF_OPT") ? atoi(getenv("EKF_OPT")) : 0;
-    fr.opt = opt;
     fr.xl_len = (int32_t)L.xl_len;
     fr.n_lm = f->n_lm;
     fr.done_ctr = f->at<unsigned long long>(L.off_done);
-    fr.dbglog = f->at<double>(L.off_log) + (size_t)(f->seq & 4095) * 8;
     f->done_total += (uint64_t)(fr.ncols / 64);
     fr.done_target = f->done_total;
     f->seq++;
@@ -767,11 +763,6 @@ int ekf_debug_fetch(ekf_filter* f, int32_t what, double* out, size_t count) {
             if (count < (size_t)k * dims) return fail(EKF_ERR_INVALID, "out too small");
             HIP_TRY(hipMemcpy2D(out, (size_t)dims * 8, f->at<double>(L.off_amat), (size_t)L.cap * 8,
                                 (size_t)dims * 8, k, hipMemcpyDeviceToHost));
-            return EKF_OK;
-        case 6:
-            if (count < 4096 * 8 + 1) return fail(EKF_ERR_INVALID, "out too small");
-            HIP_TRY(hipMemcpy(out, f->at<double>(L.off_log), (size_t)4096 * 8 * 8, hipMemcpyDeviceToHost));
-            out[4096 * 8] = (double)f->seq;
             return EKF_OK;
         case 5:
             if (count < 64) return fail(EKF_ERR_INVALID, "out too small");

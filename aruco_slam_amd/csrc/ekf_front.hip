@@ -10,12 +10,19 @@
 //                  pivot chain, publishes -L / Dinv / y block column by block column
 //   > nS + 1       one chunk of 64 columns each: A chunk into LDS, then the right-looking blocked
 //                  forward substitution in registers, consuming block column q of the factor as soon
-//                  as it is published; W chunk, dx chunk; the LAST chunk to finish injects dx into
-//                  the state (every reader of the old state has passed by then)
-// Exchange between workgroups: ekf_solve_device.h (agent-scope relaxed accesses + sentinel values;
-// no flags, no fences, no cache flushes).  The factor buffers are double-buffered across frames
-// and re-armed with sentinels by the S-block workgroups of the following frame; the S exchange has
-// a single consumer, which re-arms what it has read.
+//                  as it is published; W chunk, dx chunk, state injection for its own columns (the
+//                  only readers of the old state are workgroups 0 .. nS, which the factorisation has
+//                  waited for).  EKF_Rotations: the LAST chunk to finish injects (every landmark
+//                  carries a quaternion that straddles chunks).
+// Exchange between workgroups: ekf_solve_device.h (agent-scope relaxed accesses: write-through
+// stores, coherent loads, sentinel values; no flags, no global fences, no cache flushes).  The
+// factor buffers are double-buffered across frames and re-armed with sentinels by the S-block
+// workgroups of the following frame; the S exchange has a single consumer, which re-arms what it
+// has read.  Frame tags behind the Jacobian and behind every block column are an integrity check.
+// Rules learnt the hard way: a polled line is written by ONE full-line store;
+// one wave per workgroup polls; write-through stores stay off the pivot chain's waves; a wait for
+// a load also waits for every older store; LDS hand-overs need workgroup-scope fences, a volatile
+// flag alone is not enough; code that runs once per launch runs from a cold instruction cache.
 //
 // Arithmetic and its order are those of the stand-alone gather / solve / panel kernels
 // (ekf_small_kernels.hip): results are bitwise identical (tests/test_hip_parity.py).
@@ -32,8 +39,9 @@ __device__ __forceinline__ void ekf_poll_sleep() { __builtin_amdgcn_s_sleep(4); 
 __device__ __forceinline__ double ekf_ldt(const double* p, bool /*coherent*/) { return ekf_ldc(p); }
 
 // ---------------------------------------------------------------------------------------------
-// measurement model of every detection into LDS (one thread per detection), shared by the S-block
-// and the chunk role.  `publish`: the workgroup that also leaves jac / resid / lmcol in memory.
+// measurement model of every detection into LDS (one thread per detection), shared by the measurement
+// and the S-block role.  `publish`: also leave jac / resid / lmcol in memory (ekf_debug_fetch) and
+// the residual in LDS for the publication.
 // ---------------------------------------------------------------------------------------------
 template <int MODEL>
 __device__ __forceinline__ void fr_measure(const EkfFrame& fr, const double* cam, const int* lmc, double* hs,

@@ -62,10 +62,8 @@ struct EkfFrame {
     int32_t n_lm;              // landmarks in the state (model 1 injection)
     unsigned long long* done_ctr;      // chunks finished since reset (device)
     unsigned long long done_target;    // value of done_ctr once this frame's last chunk is done
-    double* dbglog;                    // diagnostics: 8 doubles per frame
-    int32_t xl_tag;                    // diagnostics: frame tags inside xl ([0] Jacobian, [1 + q] block column q)
+    int32_t xl_tag;                    // frame tags inside xl ([0] Jacobian, [1 + q] block column q): integrity check
     double seqno;                      // this frame's tag
-    int32_t opt;                       // experiment switches (diagnostics)
 };
 
 // fused gather + solve + panel (+ injection); see ekf_front.hip

@@ -275,11 +275,6 @@ class HipEkf:
         dummy = np.zeros(1)
         self._check(self.lib.ekf_debug_fetch(self.h, -1, _dptr(dummy), 1))
 
-    def debug_log(self):
-        out = np.zeros(4096 * 8 + 1)
-        self._check(self.lib.ekf_debug_fetch(self.h, 6, _dptr(out), out.size))
-        return out[:-1].reshape(4096, 8), int(out[-1])
-
     def debug_fetch(self, what: str, m: int):
         rd = self.rows_per_detection
         k, kp, n = rd * m, -(-rd * m // 16) * 16, self.dims

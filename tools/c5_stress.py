@@ -29,11 +29,6 @@ def run(fused, ref=None):
             f.backend.sync()
         except Exception as e:
             print("  chunk", c, "error:", str(e)[60:260])
-            log, seq = f.backend.debug_log()
-            np.set_printoptions(linewidth=200, precision=6)
-            print("  frames enqueued", seq, "; log rows [S00 r0 S11 P00 x0 J00 S(17,3) Pll] of the chunk:")
-            for q in range(seq - CH, seq):
-                print("   ", q, log[q & 4095])
             return out
         st = f.backend.get_state()
         if ref is not None and not np.array_equal(st, ref[c]):
