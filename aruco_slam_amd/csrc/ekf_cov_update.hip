@@ -25,6 +25,7 @@
 //                  (N^2 k), P is read once per lower tile and written once.
 //                  f32: v_mfma_f32_32x32x2_f32, one accumulator.
 //                  f64: v_mfma_f64_16x16x4_f64, 2x2 accumulators.
+#include <hip/hip_ext.h>
 #include "ekf_kernels.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -388,10 +389,10 @@ static inline int ekf_tri_items(const EkfFrame& fr) {
 }
 
 template <>
-void ekf_launch_cov_update<float>(const EkfFrame& fr, int variant, hipStream_t s) {
+void ekf_launch_cov_update<float>(const EkfFrame& fr, int variant, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     if (variant == 1) {
-        hipLaunchKernelGGL(ekf_cov_update_valu<float>, dim3(fr.ncols / 64, fr.ncols / 64), dim3(256),
-                           0, s, fr);
+        hipExtLaunchKernelGGL(ekf_cov_update_valu<float>, dim3(fr.ncols / 64, fr.ncols / 64), dim3(256),
+                              0, s, e0, e1, 0, fr);
     } else {
         const int items = ekf_tri_items(fr);
         const dim3 grid((items + 3) / 4), block(256);
@@ -399,24 +400,24 @@ void ekf_launch_cov_update<float>(const EkfFrame& fr, int variant, hipStream_t s
             // The kernel counts its own loads (s_waitcnt by hand), so it must not spill: 5 waves per SIMD
             // (96 registers) up to k = 128, 4 waves (128 registers) above, where hipcc needs a few more
             // (tests/test_host_cpu.py checks the spill count of every instantiation).
-#define EKF_COV_CASE(KB) case KB: hipLaunchKernelGGL((ekf_cov_update_mfma_f32<KB, 3, (KB <= 8) ? 5 : 4>), grid, block, 0, s, fr, items); break;
+#define EKF_COV_CASE(KB) case KB: hipExtLaunchKernelGGL((ekf_cov_update_mfma_f32<KB, 3, (KB <= 8) ? 5 : 4>), grid, block, 0, s, e0, e1, 0, fr, items); break;
             EKF_COV_CASE(1) EKF_COV_CASE(2) EKF_COV_CASE(3) EKF_COV_CASE(4) EKF_COV_CASE(5) EKF_COV_CASE(6)
             EKF_COV_CASE(7) EKF_COV_CASE(8) EKF_COV_CASE(9) EKF_COV_CASE(10) EKF_COV_CASE(11)
-            default: hipLaunchKernelGGL((ekf_cov_update_mfma_f32<12, 3, 4>), grid, block, 0, s, fr, items); break;
+            default: hipExtLaunchKernelGGL((ekf_cov_update_mfma_f32<12, 3, 4>), grid, block, 0, s, e0, e1, 0, fr, items); break;
 #undef EKF_COV_CASE
         }
     }
 }
 template <>
-void ekf_launch_cov_update<double>(const EkfFrame& fr, int variant, hipStream_t s) {
+void ekf_launch_cov_update<double>(const EkfFrame& fr, int variant, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     if (variant == 1) {
-        hipLaunchKernelGGL(ekf_cov_update_valu<double>, dim3(fr.ncols / 64, fr.ncols / 64),
-                           dim3(256), 0, s, fr);
+        hipExtLaunchKernelGGL(ekf_cov_update_valu<double>, dim3(fr.ncols / 64, fr.ncols / 64),
+                              dim3(256), 0, s, e0, e1, 0, fr);
     } else {
         const int items = ekf_tri_items(fr);
         if (items <= 2048)      // small problem: one workgroup per tile, one 16x16 sub-tile per wave
-            hipLaunchKernelGGL(ekf_cov_update_mfma_f64_split, dim3(items), dim3(256), 0, s, fr, items);
+            hipExtLaunchKernelGGL(ekf_cov_update_mfma_f64_split, dim3(items), dim3(256), 0, s, e0, e1, 0, fr, items);
         else
-            hipLaunchKernelGGL(ekf_cov_update_mfma_f64, dim3((items + 3) / 4), dim3(256), 0, s, fr, items);
+            hipExtLaunchKernelGGL(ekf_cov_update_mfma_f64, dim3((items + 3) / 4), dim3(256), 0, s, e0, e1, 0, fr, items);
     }
 }

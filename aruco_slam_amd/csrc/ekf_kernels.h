@@ -74,7 +74,9 @@ template <typename T> void ekf_launch_gather(const EkfFrame& fr, hipStream_t s);
 void ekf_launch_solve(const EkfFrame& fr, hipStream_t s);
 template <typename T> void ekf_launch_panel(const EkfFrame& fr, hipStream_t s);
 // P <- P + Q - W^T W.  variant: 1 = VALU reference kernel, 2 = MFMA kernel.
-template <typename T> void ekf_launch_cov_update(const EkfFrame& fr, int variant, hipStream_t s);
+// e0 / e1 (optional): events that receive the kernel's own start / stop time stamps (hipExtLaunchKernelGGL)
+template <typename T> void ekf_launch_cov_update(const EkfFrame& fr, int variant, hipStream_t s,
+                                                 hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 template <typename T> void ekf_launch_cov_rows(const EkfFrame& fr, hipStream_t s);
 
 template <typename T>
