@@ -169,11 +169,11 @@ def main():
     assert all_traj.shape == (world, k_steps, 7) and all_map.shape == (world, n, 6)
 
     # ---- instrumented repeat: per-kernel HIP-event timing on the filter stream -
-    # pass A: the covariance-update kernel alone (2 events / frame) -> roofline
+    # pass A: the covariance-update kernel alone (start / stop events attached to its dispatch) -> roofline
     hip.set_kernel_timing(2)
     run(w_steps + k_steps, w_steps + 2 * k_steps)
     cov_us, cov_launches = hip.kernel_timing()["cov_update"]
-    # pass B: all four kernels (5 events / frame; each interval also holds a launch gap)
+    # pass B: every kernel (front kernel: events recorded around the launch, i.e. including its launch gap)
     hip.set_kernel_timing(1)
     run(w_steps + 2 * k_steps, total)
     timing = hip.kernel_timing()
@@ -197,7 +197,7 @@ def main():
     achieved = algo_bytes / (cov_us * 1e-6) / 1e9 if cov_us > 0 else 0.0
     # HBM bytes per launch from rocprofv3 PMC passes (tools/profile_round.sh +
     # tools/summarize_profile.py), and the rocprofv3 kernel-trace duration next to the
-    # HIP-event one (events bracket the launch, so they also hold the dispatch gap)
+    # HIP-event one (dispatch time stamps; they start a little before the first wave does)
     traffic = rocprof_us = None
     pmc = REPO / "profiles" / "cov_update_pmc_traffic.json"
     if pmc.exists():
