@@ -449,11 +449,13 @@ __device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, int RS, doubl
                 const double y = ekf_rsqrt_f64(d);
                 const double lj = a[j] * y;
                 a[j] = lj;
+                // broadcasts first, updates second: back-to-back v_readlane into distinct scalar registers,
+                // no wait states between a broadcast and the fma that consumes it
+                double lx[EKF_RB];
 #pragma unroll
-                for (int x = j + 1; x < EKF_RB; ++x) {
-                    const double lx = ekf_readlane_f64(lj, x);
-                    a[x] = __builtin_fma(-lj, lx, a[x]);
-                }
+                for (int x = j + 1; x < EKF_RB; ++x) lx[x] = ekf_readlane_f64(lj, x);
+#pragma unroll
+                for (int x = j + 1; x < EKF_RB; ++x) a[x] = __builtin_fma(-lj, lx[x], a[x]);
             }
             if (bad && !badb) badb = 100 + b;                                      // diagnostics: first bad block column
             if (live) {
