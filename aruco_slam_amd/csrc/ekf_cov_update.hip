@@ -383,6 +383,13 @@ void ekf_launch_cov_rows(const EkfFrame& fr, hipStream_t s) {
 template void ekf_launch_cov_rows<float>(const EkfFrame&, hipStream_t);
 template void ekf_launch_cov_rows<double>(const EkfFrame&, hipStream_t);
 
+// plain launch; with events attached, the dispatch's own start / stop time stamps land in e0 / e1
+#define EKF_COV_LAUNCH(kernel, grid, block, s, e0, e1, ...)                                     \
+    do {                                                                                         \
+        if (e0) hipExtLaunchKernelGGL(kernel, grid, block, 0, s, e0, e1, 0, __VA_ARGS__);        \
+        else hipLaunchKernelGGL(kernel, grid, block, 0, s, __VA_ARGS__);                         \
+    } while (0)
+
 static inline int ekf_tri_items(const EkfFrame& fr) {
     const int t = (fr.dims + 31) / 32;                // 32 t <= ncols <= ld
     return t * (t + 1) / 2;
@@ -391,8 +398,7 @@ static inline int ekf_tri_items(const EkfFrame& fr) {
 template <>
 void ekf_launch_cov_update<float>(const EkfFrame& fr, int variant, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     if (variant == 1) {
-        hipExtLaunchKernelGGL(ekf_cov_update_valu<float>, dim3(fr.ncols / 64, fr.ncols / 64), dim3(256),
-                              0, s, e0, e1, 0, fr);
+        EKF_COV_LAUNCH(ekf_cov_update_valu<float>, dim3(fr.ncols / 64, fr.ncols / 64), dim3(256), s, e0, e1, fr);
     } else {
         const int items = ekf_tri_items(fr);
         const dim3 grid((items + 3) / 4), block(256);
@@ -400,10 +406,10 @@ void ekf_launch_cov_update<float>(const EkfFrame& fr, int variant, hipStream_t s
             // The kernel counts its own loads (s_waitcnt by hand), so it must not spill: 5 waves per SIMD
             // (96 registers) up to k = 128, 4 waves (128 registers) above, where hipcc needs a few more
             // (tests/test_host_cpu.py checks the spill count of every instantiation).
-#define EKF_COV_CASE(KB) case KB: hipExtLaunchKernelGGL((ekf_cov_update_mfma_f32<KB, 3, (KB <= 8) ? 5 : 4>), grid, block, 0, s, e0, e1, 0, fr, items); break;
+#define EKF_COV_CASE(KB) case KB: EKF_COV_LAUNCH((ekf_cov_update_mfma_f32<KB, 3, (KB <= 8) ? 5 : 4>), grid, block, s, e0, e1, fr, items); break;
             EKF_COV_CASE(1) EKF_COV_CASE(2) EKF_COV_CASE(3) EKF_COV_CASE(4) EKF_COV_CASE(5) EKF_COV_CASE(6)
             EKF_COV_CASE(7) EKF_COV_CASE(8) EKF_COV_CASE(9) EKF_COV_CASE(10) EKF_COV_CASE(11)
-            default: hipExtLaunchKernelGGL((ekf_cov_update_mfma_f32<12, 3, 4>), grid, block, 0, s, e0, e1, 0, fr, items); break;
+            default: EKF_COV_LAUNCH((ekf_cov_update_mfma_f32<12, 3, 4>), grid, block, s, e0, e1, fr, items); break;
 #undef EKF_COV_CASE
         }
     }
@@ -411,13 +417,12 @@ void ekf_launch_cov_update<float>(const EkfFrame& fr, int variant, hipStream_t s
 template <>
 void ekf_launch_cov_update<double>(const EkfFrame& fr, int variant, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     if (variant == 1) {
-        hipExtLaunchKernelGGL(ekf_cov_update_valu<double>, dim3(fr.ncols / 64, fr.ncols / 64),
-                              dim3(256), 0, s, e0, e1, 0, fr);
+        EKF_COV_LAUNCH(ekf_cov_update_valu<double>, dim3(fr.ncols / 64, fr.ncols / 64), dim3(256), s, e0, e1, fr);
     } else {
         const int items = ekf_tri_items(fr);
         if (items <= 2048)      // small problem: one workgroup per tile, one 16x16 sub-tile per wave
-            hipExtLaunchKernelGGL(ekf_cov_update_mfma_f64_split, dim3(items), dim3(256), 0, s, e0, e1, 0, fr, items);
+            EKF_COV_LAUNCH(ekf_cov_update_mfma_f64_split, dim3(items), dim3(256), s, e0, e1, fr, items);
         else
-            hipExtLaunchKernelGGL(ekf_cov_update_mfma_f64, dim3((items + 3) / 4), dim3(256), 0, s, e0, e1, 0, fr, items);
+            EKF_COV_LAUNCH(ekf_cov_update_mfma_f64, dim3((items + 3) / 4), dim3(256), s, e0, e1, fr, items);
     }
 }
