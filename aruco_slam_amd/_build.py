@@ -35,14 +35,20 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     hdrs = [CSRC / h for h in HEADERS]
     objs = []
     flags = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+    jobs = []
     for src in SOURCES:
         obj = obj_dir / (Path(src).stem + ".o")
         if force or _stale(obj, [CSRC / src, *hdrs]):
-            cmd = [hipcc(), *flags, "-c", str(CSRC / src), "-o", str(obj)]
+            jobs.append([hipcc(), *flags, "-c", str(CSRC / src), "-o", str(obj)])
+        objs.append(obj)
+    if jobs:        # the translation units are independent: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd))
             subprocess.run(cmd, check=True)
-        objs.append(obj)
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as pool:
+            list(pool.map(run, jobs))
     if force or _stale(LIB_PATH, objs):
         cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB_PATH),
                *map(str, objs)]

@@ -720,7 +720,7 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
     if (stp) stp[NB] = wall_clock64();
 }
 
-template <typename T, int NU, int MODEL>
+template <typename T, int NU, int MODEL, int NB>
 __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, double* sm) {
     constexpr int RD = EkfModel<MODEL>::RD, LMD = EkfModel<MODEL>::LMD, JC = EkfModel<MODEL>::JC;
     constexpr int NWV = FR_T / 64;
@@ -812,13 +812,7 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
     int spin_fail = 0;
     if (g < 4) {
         const int lane = tid & 63, col0 = chunk0 + 16 * g;
-        switch (fr.kpad / EKF_RB) {
-#define FR_CASE(NB) case NB: fr_panel<T, NB, MODEL>(fr, a_lds, flag + 1, pshare, g, col0, lane, spin_fail); break;
-            FR_CASE(1) FR_CASE(2) FR_CASE(3) FR_CASE(4) FR_CASE(5) FR_CASE(6)
-            FR_CASE(7) FR_CASE(8) FR_CASE(9) FR_CASE(10) FR_CASE(11)
-            default: fr_panel<T, 12, MODEL>(fr, a_lds, flag + 1, pshare, g, col0, lane, spin_fail); break;
-#undef FR_CASE
-        }
+        fr_panel<T, NB, MODEL>(fr, a_lds, flag + 1, pshare, g, col0, lane, spin_fail);
         if (spin_fail && (tid & 63) == 0) atomicOr(fr.status, 4);
     }
     if (MODEL == 0) return;
@@ -854,7 +848,9 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
     }
 }
 
-template <typename T, int NU, int MODEL>
+// One instantiation per number of 16-row blocks NB = kpad / 16: the forward substitution is unrolled
+// over NB, and a kernel that carried all twelve variants spilled registers.
+template <typename T, int NU, int MODEL, int NB>
 __global__ __launch_bounds__(FR_T) void ekf_front_kernel(EkfFrame fr, int RS) {
     extern __shared__ __attribute__((aligned(16))) double fr_sm[];
     const int nb = fr.kpad / EKF_RB, nS = nb * (nb + 1) / 2;
@@ -862,16 +858,16 @@ __global__ __launch_bounds__(FR_T) void ekf_front_kernel(EkfFrame fr, int RS) {
     if (bx == 0) fr_role_measure<MODEL>(fr, fr_sm);
     else if (bx <= nS) fr_role_sblock<T, MODEL>(fr, bx - 1, nS, fr_sm);
     else if (bx == nS + 1) fr_role_factor(fr, RS, fr_sm);
-    else fr_role_chunk<T, NU, MODEL>(fr, bx - nS - 2, fr_sm);
+    else fr_role_chunk<T, NU, MODEL, NB>(fr, bx - nS - 2, fr_sm);
 }
 
-template <typename T, int NU, int MODEL>
+template <typename T, int NU, int MODEL, int NB>
 static void ekf_front_go(const EkfFrame& fr, hipStream_t s) {
     constexpr int LMD = EkfModel<MODEL>::LMD, JC = EkfModel<MODEL>::JC;
     constexpr int NSLOT = EKF_CAM + LMD * EkfModel<MODEL>::NDET16;
     static bool once = false;
     if (!once) {   // > 64 KB of dynamic LDS needs the opt-in
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ekf_front_kernel<T, NU, MODEL>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ekf_front_kernel<T, NU, MODEL, NB>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         once = true;
     }
@@ -881,15 +877,32 @@ static void ekf_front_go(const EkfFrame& fr, hipStream_t s) {
     const size_t lds_f = (size_t)ekf_solve_stream_lds_bytes(fr.kpad, fr.k) + 2 * 16 * 17 * 8;
     size_t lds = lds_s > lds_c ? lds_s : lds_c;
     if (lds_f > lds) lds = lds_f;
-    hipLaunchKernelGGL((ekf_front_kernel<T, NU, MODEL>), dim3(nS + 2 + fr.ncols / 64), dim3(FR_T), lds, s, fr,
+    hipLaunchKernelGGL((ekf_front_kernel<T, NU, MODEL, NB>), dim3(nS + 2 + fr.ncols / 64), dim3(FR_T), lds, s, fr,
                        ekf_solve_stream_ring(fr.kpad, fr.k));
 }
 
 template <typename T>
 void ekf_launch_front(const EkfFrame& fr, hipStream_t s) {
-    if (fr.model == 1) return ekf_front_go<T, 4, 1>(fr, s);      // m <= 27
-    if (fr.m <= 32) return ekf_front_go<T, 4, 0>(fr, s);
-    return ekf_front_go<T, 8, 0>(fr, s);
+    const int nb = fr.kpad / EKF_RB;
+#define FR_GO(NU, MODEL, NB) case NB: return ekf_front_go<T, NU, MODEL, NB>(fr, s);
+    if (fr.model == 1) {                 // EKF_Rotations: m <= 27, k = 7 m
+        switch (nb) {
+            FR_GO(4, 1, 1) FR_GO(4, 1, 2) FR_GO(4, 1, 3) FR_GO(4, 1, 4) FR_GO(4, 1, 5) FR_GO(4, 1, 6)
+            FR_GO(4, 1, 7) FR_GO(4, 1, 8) FR_GO(4, 1, 9) FR_GO(4, 1, 10) FR_GO(4, 1, 11)
+            default: return ekf_front_go<T, 4, 1, 12>(fr, s);
+        }
+    }
+    if (fr.m <= 32) {                    // k = 3 m <= 96
+        switch (nb) {
+            FR_GO(4, 0, 1) FR_GO(4, 0, 2) FR_GO(4, 0, 3) FR_GO(4, 0, 4) FR_GO(4, 0, 5)
+            default: return ekf_front_go<T, 4, 0, 6>(fr, s);
+        }
+    }
+    switch (nb) {                        // m = 33 .. 64: k = 99 .. 192
+        FR_GO(8, 0, 7) FR_GO(8, 0, 8) FR_GO(8, 0, 9) FR_GO(8, 0, 10) FR_GO(8, 0, 11)
+        default: return ekf_front_go<T, 8, 0, 12>(fr, s);
+    }
+#undef FR_GO
 }
 template void ekf_launch_front<float>(const EkfFrame&, hipStream_t);
 template void ekf_launch_front<double>(const EkfFrame&, hipStream_t);
