@@ -1,908 +1,4 @@
-// Fused "front" kernel of the EKF update (gfx950): measurement model, A = H (P+Q),
-// S = Hs (P+Q) Hs^T + R, blocked Cholesky, W = L^-1 A, dx = W^T y and the state injection in ONE
-// launch (reference: extended_kalman_filter.py:107-152; ekf_with_rotations.py:115-177).
-//
-// Workgroup roles by blockIdx.x (a workgroup only ever waits for LOWER-indexed workgroups, which
-// the dispatcher starts first, so the waits cannot deadlock whatever the residency):
-//   0              measurement model: Jacobian rows / residual for the other roles
-//   [1, nS]        one 16x16 block of S each, straight from P (nS = nb (nb+1) / 2)
-//   nS + 1         the factorisation: streams the S blocks into LDS as they appear, runs the
-//                  pivot chain, publishes -L / Dinv / y block column by block column
-//   > nS + 1       one chunk of 64 columns each: A chunk into LDS, then the right-looking blocked
-//                  forward substitution in registers, consuming block column q of the factor as soon
-//                  as it is published; W chunk, dx chunk, state injection for its own columns (the
-//                  only readers of the old state are workgroups 0 .. nS, which the factorisation has
-//                  waited for).  EKF_Rotations: the LAST chunk to finish injects (every landmark
-//                  carries a quaternion that straddles chunks).
-// Exchange between workgroups: ekf_solve_device.h (agent-scope relaxed accesses: write-through
-// stores, coherent loads, sentinel values; no flags, no global fences, no cache flushes).  The
-// factor buffers are double-buffered across frames and re-armed with sentinels by the S-block
-// workgroups of the following frame; the S exchange has a single consumer, which re-arms what it
-// has read.  Frame tags behind the Jacobian and behind every block column are an integrity check.
-// Rules learnt the hard way: a polled line is written by ONE full-line store;
-// one wave per workgroup polls; write-through stores stay off the pivot chain's waves; a wait for
-// a load also waits for every older store; LDS hand-overs need workgroup-scope fences, a volatile
-// flag alone is not enough; code that runs once per launch runs from a cold instruction cache.
-//
-// Arithmetic and its order are those of the stand-alone gather / solve / panel kernels
-// (ekf_small_kernels.hip): results are bitwise identical (tests/test_hip_parity.py).
-#include "ekf_solve_device.h"
+// Fused front kernel, float covariance instantiations (see ekf_front_impl.h).
+#include "ekf_front_impl.h"
 
-#define FR_T 512
-#define FR_ALD 66          // row stride (doubles) of the A chunk in LDS
-
-typedef double pf64x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void ekf_poll_sleep() { __builtin_amdgcn_s_sleep(4); }
-// every exchange read is a coherent load (`coherent` kept for readability at the call sites: first
-// attempt vs retry)
-__device__ __forceinline__ double ekf_ldt(const double* p, bool /*coherent*/) { return ekf_ldc(p); }
-
-// ---------------------------------------------------------------------------------------------
-// measurement model of every detection into LDS (one thread per detection), shared by the measurement
-// and the S-block role.  `publish`: also leave jac / resid / lmcol in memory (ekf_debug_fetch) and
-// the residual in LDS for the publication.
-// ---------------------------------------------------------------------------------------------
-template <int MODEL>
-__device__ __forceinline__ void fr_measure(const EkfFrame& fr, const double* cam, const int* lmc, double* hs,
-                                           double* rsd, int tid, bool publish) {
-    constexpr int RD = EkfModel<MODEL>::RD, LMD = EkfModel<MODEL>::LMD, JC = EkfModel<MODEL>::JC;
-    if (tid < fr.m) {
-        const int c0 = lmc[tid];
-        double lm[LMD], h[RD], J[RD][JC];
-        for (int d = 0; d < LMD; ++d) lm[d] = fr.state[c0 + d];
-        ekf_measure_model<MODEL>(cam, lm, h, J);
-        for (int d = 0; d < RD; ++d)
-            for (int a = 0; a < JC; ++a) hs[(RD * tid + d) * JC + a] = J[d][a];
-        if (publish) {
-            for (int d = 0; d < RD; ++d) {
-                for (int a = 0; a < JC; ++a) fr.jac[(size_t)(RD * tid + d) * EKF_JLD + a] = J[d][a];
-                const double rv = fr.z[RD * tid + d] - h[d];          // additive residual (:140)
-                fr.resid[RD * tid + d] = rv;
-                rsd[RD * tid + d] = rv;
-            }
-            fr.lmcol[tid] = c0;
-        }
-    }
-    if (publish)
-        for (int r = fr.k + tid; r < fr.kpad; r += FR_T) rsd[r] = 0.0;
-}
-
-// ---------------------------------------------------------------------------------------------
-// role: one block of S
-// ---------------------------------------------------------------------------------------------
-template <typename T, int MODEL>
-__device__ __forceinline__ void fr_role_sblock(const EkfFrame& fr, int sb, int nS, double* sm) {
-    constexpr int RD = EkfModel<MODEL>::RD, LMD = EkfModel<MODEL>::LMD, JC = EkfModel<MODEL>::JC;
-    constexpr int NSLOT = EKF_CAM + LMD * EkfModel<MODEL>::NDET16;
-    double* hs = sm;                                    // [k][JC]
-    double* us = sm + fr.k * JC;                        // [NSLOT][16]
-    int* lmc = reinterpret_cast<int*>(us + NSLOT * 16);
-    double* rsd = us + NSLOT * 16 + 32;                 // [kpad] z - h (workgroup 0 only)
-    const int tid = threadIdx.x, m = fr.m, k = fr.k;
-    const T* __restrict__ P = static_cast<const T*>(fr.cov);
-    const T* __restrict__ prow = static_cast<const T*>(fr.prow);
-    const int64_t ld = fr.ld;
-    double cam[EKF_CAM];
-#pragma unroll
-    for (int a = 0; a < EKF_CAM; ++a) cam[a] = fr.state[a];
-    if (fr.stamps && sb == 0 && tid == 0) fr.stamps[60] = wall_clock64();
-    if (tid < m) lmc[tid] = EKF_CAM + LMD * fr.idx[tid];
-    __syncthreads();
-    // this thread's entry of U (slot, c2): its P values are requested before the measurement model
-    // is evaluated, so the two dependent memory round trips overlap
-    int bi = 0, bj = sb;
-    while (bj > bi) { bj -= bi + 1; ++bi; }
-    const int j0 = (16 * bi) / RD;
-    constexpr int NE = (NSLOT * 16 + FR_T - 1) / FR_T;  // entries of U per thread (1 or 2)
-    int urho[NE], uc20[NE], ur2[NE];
-    bool uact[NE];
-    T pv[NE][JC];
-#pragma unroll
-    for (int n = 0; n < NE; ++n) {
-        const int ue = tid + FR_T * n;
-        const int uslot = ue >> 4, uc2 = ue & 15;
-        ur2[n] = 16 * bj + uc2;
-        const int uj = j0 + (uslot - EKF_CAM) / LMD, ud = (uslot - EKF_CAM) % LMD;
-        uact[n] = ue < NSLOT * 16 && ur2[n] < k && (uslot < EKF_CAM || uj < m);
-        urho[n] = 0;
-        uc20[n] = 0;
-        if (uact[n]) {
-            urho[n] = (uslot < EKF_CAM) ? uslot : lmc[uj] + ud;
-            const T* prw = prow ? prow + (int64_t)((uslot < EKF_CAM) ? uslot : EKF_CAM + LMD * uj + ud) * fr.ldw
-                                : P + (int64_t)urho[n] * ld;
-            uc20[n] = lmc[ur2[n] / RD];
-#pragma unroll
-            for (int b = 0; b < EKF_CAM; ++b) pv[n][b] = prw[b];
-#pragma unroll
-            for (int b = 0; b < LMD; ++b) pv[n][EKF_CAM + b] = prw[uc20[n] + b];
-        }
-    }
-    fr_measure<MODEL>(fr, cam, lmc, hs, rsd, tid, false);
-    __syncthreads();
-#pragma unroll
-    for (int n = 0; n < NE; ++n) {
-        const int ue = tid + FR_T * n;
-        if (ue < NSLOT * 16) {
-            double acc = 0.0;
-            if (uact[n]) {
-                const double* h2 = hs + ur2[n] * JC;
-#pragma unroll
-                for (int b = 0; b < JC; ++b) {
-                    const int col = (b < EKF_CAM) ? b : uc20[n] + (b - EKF_CAM);
-                    const double pq = (double)pv[n][b] + ((col == urho[n]) ? ekf_qdiag(urho[n], fr.dims, fr.nz) : 0.0);
-                    acc = __builtin_fma(pq, h2[b], acc);
-                }
-            }
-            us[ue] = acc;
-        }
-    }
-    __syncthreads();
-    if (tid < 256) {
-        const int i = tid >> 4, c2 = tid & 15, r1 = 16 * bi + i, r2 = 16 * bj + c2;
-        double v;
-        if (r1 >= k || r2 >= k) {
-            v = (r1 == r2) ? 1.0 : 0.0;
-        } else if (r2 > r1) {
-            v = 0.0;
-        } else {
-            const double* h1 = hs + r1 * JC;
-            const int s1 = EKF_CAM + LMD * (r1 / RD - j0);
-            double acc = (r1 == r2) ? fr.nz.r_unc : 0.0;
-#pragma unroll
-            for (int a = 0; a < EKF_CAM; ++a) acc = __builtin_fma(h1[a], us[a * 16 + c2], acc);
-#pragma unroll
-            for (int d = 0; d < LMD; ++d) acc = __builtin_fma(h1[EKF_CAM + d], us[(s1 + d) * 16 + c2], acc);
-            v = acc;
-        }
-        ekf_stc(fr.xs + ((size_t)bj * fr.sblk_rows + r1) * 16 + c2, v);
-    }
-    if (fr.stamps && sb == nS - 1 && tid == 0) fr.stamps[61] = wall_clock64();
-
-    // re-arm the factor exchange buffer of the NEXT frame (the one frame t-1 used)
-    {
-        const int64_t lo = (int64_t)fr.xl_len * sb / nS, hi = (int64_t)fr.xl_len * (sb + 1) / nS;
-        const double sent = ekf_sent();
-        for (int64_t e = lo + tid; e < hi; e += FR_T) ekf_stc(fr.xl_next + e, sent);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// role: measurement model for the other roles (workgroup 0): Jacobian rows for the chunks, residual
-// for the factorisation, plus the copies that ekf_debug_fetch reads.  Its own workgroup, so that no
-// S block is delayed by the publication.
-// ---------------------------------------------------------------------------------------------
-template <int MODEL>
-__device__ __forceinline__ void fr_role_measure(const EkfFrame& fr, double* sm) {
-    constexpr int LMD = EkfModel<MODEL>::LMD, JC = EkfModel<MODEL>::JC;
-    double* hs = sm;                                    // [k][JC]
-    double* rsd = sm + fr.k * JC;                       // [kpad]
-    int* lmc = reinterpret_cast<int*>(rsd + fr.kpad);
-    const int tid = threadIdx.x;
-    double cam[EKF_CAM];
-#pragma unroll
-    for (int a = 0; a < EKF_CAM; ++a) cam[a] = fr.state[a];
-    if (tid < fr.m) lmc[tid] = EKF_CAM + LMD * fr.idx[tid];
-    __syncthreads();
-    fr_measure<MODEL>(fr, cam, lmc, hs, rsd, tid, true);
-    __syncthreads();
-    // whole cache lines per store instruction (a line that is polled must not be written piecemeal)
-    double* __restrict__ xj = fr.xl + fr.xl_jac;
-    const int nel = fr.k * JC;
-    for (int e = tid; e < nel; e += FR_T) ekf_stc(xj + e, hs[e]);
-    for (int e = tid; e < fr.kpad; e += FR_T) ekf_stc(fr.xr + e, rsd[e]);
-    if (tid == 0) ekf_stc(fr.xl + fr.xl_tag, fr.seqno);
-    if (fr.stamps && tid == 0) fr.stamps[55] = wall_clock64();
-}
-
-// ---------------------------------------------------------------------------------------------
-// role: factorisation (the stand-alone solve kernel with exchange-buffer input / output)
-// ---------------------------------------------------------------------------------------------
-// One 16x16 block of S (row block i of block column tc; i == nb: the residual row) travels from the
-// exchange buffer into the factor's LDS column buffer.  Lane <-> word mapping: word x*64 + lane of the
-// 2 KB block, i.e. row 4x + (lane >> 4), column lane & 15: every load / re-arm store instruction
-// covers 512 contiguous bytes.  Polling touches ONE word (the block's last); the bulk goes through
-// cacheable loads (sc1 stores are written through, see tools/xcd_exchange_probe.hip; nothing in this
-// launch has touched those lines before; whatever has not landed yet still reads as a sentinel and
-// is re-read coherently).
-struct FrBlockSrc { double* base; const double* w; bool resid; };
-__device__ __forceinline__ FrBlockSrc fr_block_src(const EkfFrame& fr, int nb, int i, int tc, int lane) {
-    FrBlockSrc s;
-    s.resid = i >= nb;
-    if (!s.resid) {
-        s.base = fr.xs + ((size_t)tc * fr.sblk_rows + EKF_RB * i) * 16;
-        s.w = s.base + 255;
-    } else {
-        s.base = fr.xr + EKF_RB * tc;
-        s.w = s.base + 15;
-    }
-    return s;
-}
-// Lane <-> word mapping of a 2 KB block: words 128 x + 2 lane, +1 (x = 0, 1), i.e. row 8x + (lane >> 3),
-// columns 2 (lane & 7), +1.  All exchange reads are coherent (sc1) loads; their cost is per instruction
-// (~400 cycles each when eight waves fetch at once), so the bulk uses 16-byte loads, written as inline asm
-// (the atomic builtins stop at 8 bytes): issue with fr_block_issue, then ONE fr_block_arrive for the
-// whole batch before the values are used.  Retries use the 8-byte builtin.
-typedef double fr_d2 __attribute__((ext_vector_type(2)));
-struct FrBlockRaw { fr_d2 a, b; };
-__device__ __forceinline__ void fr_block_issue(FrBlockRaw& r, const FrBlockSrc& s, int lane) {
-    r.a = fr_d2{0.0, 0.0};
-    r.b = fr_d2{0.0, 0.0};
-    if (!s.resid) {
-        const double* p0 = s.base + 2 * lane;
-        const double* p1 = s.base + 128 + 2 * lane;
-        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r.a) : "v"(p0) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r.b) : "v"(p1) : "memory");
-    } else if (lane < EKF_RB) {
-        const double* p0 = s.base + lane;
-        double v;
-        asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v) : "v"(p0) : "memory");
-        r.a[0] = v;
-    }
-}
-template <int N>
-__device__ __forceinline__ void fr_block_arrive(FrBlockRaw (&r)[N]) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int j = 0; j < N; ++j) asm volatile("" : "+v"(r[j].a), "+v"(r[j].b));       // uses stay below the wait
-}
-__device__ __forceinline__ sf64x4 fr_block_value(const FrBlockRaw& r) { return sf64x4{r.a[0], r.a[1], r.b[0], r.b[1]}; }
-__device__ __forceinline__ sf64x4 fr_block_load_coherent(const FrBlockSrc& s, int lane) {
-    sf64x4 v = {0.0, 0.0, 0.0, 0.0};
-    if (!s.resid) {
-        v[0] = ekf_ldc(s.base + 2 * lane);
-        v[1] = ekf_ldc(s.base + 2 * lane + 1);
-        v[2] = ekf_ldc(s.base + 128 + 2 * lane);
-        v[3] = ekf_ldc(s.base + 128 + 2 * lane + 1);
-    } else if (lane < EKF_RB) {
-        v[0] = ekf_ldc(s.base + lane);
-    }
-    return v;
-}
-__device__ __forceinline__ sf64x4 fr_block_load(const FrBlockSrc& s, int lane) {      // single block (ring mode)
-    FrBlockRaw r[1];
-    fr_block_issue(r[0], s, lane);
-    fr_block_arrive(r);
-    return fr_block_value(r[0]);
-}
-__device__ __forceinline__ bool fr_block_pending(const sf64x4& v) {
-    const bool p = ekf_is_sent(v[0]) || ekf_is_sent(v[1]) || ekf_is_sent(v[2]) || ekf_is_sent(v[3]);
-    return __any(p);
-}
-// one word of the block, same address in every lane: has the producer's store landed?
-__device__ __forceinline__ bool fr_block_landed(const FrBlockSrc& s) { return !ekf_is_sent(ekf_ldc(s.w)); }
-__device__ __forceinline__ void fr_block_wait(const FrBlockSrc& s, int& spin_fail) {
-    int it = 0;
-    while (!fr_block_landed(s)) {
-        if (++it > EKF_SPIN_MAX) { spin_fail = 1; break; }
-        ekf_poll_sleep();
-    }
-}
-// the block's values are in `v` (cacheable attempt); anything still missing is re-read coherently
-__device__ __forceinline__ sf64x4 fr_block_settle(const FrBlockSrc& s, sf64x4 v, int lane, int& spin_fail) {
-    int it = 0;
-    while (fr_block_pending(v)) {
-        if (++it > EKF_SPIN_MAX) { spin_fail = 1; break; }
-        ekf_poll_sleep();
-        v = fr_block_load_coherent(s, lane);
-    }
-    return v;
-}
-// Re-arm (single consumer).  Issued after ALL loads of a batch have been consumed (a wait for a load
-// also waits for every older store), written through (sc1) like the data and right away: with plain
-// stores, or with the re-arm postponed to the end of the role, n >= 3700 fails in 10-30 % of the runs.
-__device__ __forceinline__ void fr_block_rearm(const FrBlockSrc& s, int lane) {
-    const double sent = ekf_sent();
-    if (!s.resid) {
-#pragma unroll
-        for (int x = 0; x < 4; ++x) ekf_stc(s.base + x * 64 + lane, sent);     // whole cache lines per instruction
-    } else if (lane < EKF_RB) {
-        ekf_stc(s.base + lane, sent);
-    }
-}
-__device__ __forceinline__ sf64x4 fr_block_take(const FrBlockSrc& s, sf64x4 v, int lane, int& spin_fail) {
-    v = fr_block_settle(s, v, lane, spin_fail);
-    fr_block_rearm(s, lane);
-    return v;
-}
-__device__ __forceinline__ void fr_block_put(const sf64x4& v, double* tgt, int kp, int nb, int i, int lane) {
-    if (i < nb) {
-        const fr_d2 a = {v[0], v[1]}, b = {v[2], v[3]};
-        *reinterpret_cast<fr_d2*>(tgt + (EKF_RB * i + (lane >> 3)) * SV_CLD + 2 * (lane & 7)) = a;
-        *reinterpret_cast<fr_d2*>(tgt + (EKF_RB * i + 8 + (lane >> 3)) * SV_CLD + 2 * (lane & 7)) = b;
-    } else if (lane < EKF_RB) {
-        tgt[kp * SV_CLD + lane] = v[0];
-    }
-}
-
-__device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, int RS, double* v_sm) {
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
-    const int kp = fr.kpad, nb = kp / EKF_RB, rows = kp + 1;
-    double* ring = v_sm;                                         // [RS][rows][SV_CLD]
-    double* dscr0 = v_sm + (size_t)RS * rows * SV_CLD + 8;       // [2][16][17] Dinv of block column b (slot b & 1)
-    const bool all_resident = RS >= nb;
-    auto colbuf = [&](int col) { return ring + (size_t)(col % RS) * rows * SV_CLD; };
-    constexpr int NW = FR_T / 64;
-    double* __restrict__ xlop = fr.xl;
-    double* __restrict__ xdop = fr.xl + fr.xl_dop;
-    double* __restrict__ xy = fr.xl + fr.xl_y;
-    int nstamp = 0, spin_fail = 0;
-#define EKF_STAMP() do { if (fr.stamps && tid == 0) fr.stamps[nstamp] = clock64(); ++nstamp; } while (0)
-    if (fr.stamps && tid == 0) fr.stamps[62] = wall_clock64();
-    EKF_STAMP();
-    constexpr int PB = 4;       // (small on purpose: this code runs once per launch, i.e. from a cold instruction cache)
-    // block columns brought into LDS before the first pivot chain: only column 0 when all columns stay
-    // resident (the others arrive during iteration 0, whose free waves have nothing else to do; later
-    // iterations have no slack for memory round trips), else 0 and 1 (column c >= 2 then arrives
-    // during iteration c - 2)
-    const int ncol0 = all_resident ? 1 : (nb > 1 ? 2 : 1);
-    int ntot = 0;
-    for (int tc = 0; tc < ncol0; ++tc) ntot += nb - tc + 1;
-    sf64x4 pv[PB];
-    FrBlockSrc ps[PB];
-    int pi[PB], ptc[PB];
-#pragma unroll
-    for (int j = 0; j < PB; ++j) {
-        int u = wave + NW * j, tc = 0;
-        const bool has = u < ntot;
-        u = has ? u : 0;
-        while (u >= nb - tc + 1) { u -= nb - tc + 1; ++tc; }
-        pi[j] = has ? tc + u : -1;
-        ptc[j] = tc;
-        ps[j] = fr_block_src(fr, nb, tc + u, tc, lane);
-    }
-    EKF_STAMP();
-    {   // poll one word per block, all blocks of this wave together
-        int it = 0;
-        for (;;) {
-            bool pend = false;
-#pragma unroll
-            for (int j = 0; j < PB; ++j)
-                if (pi[j] >= 0) pend = pend | !fr_block_landed(ps[j]);      // (no short circuit: loads together)
-            if (!pend) break;
-            if (++it > EKF_SPIN_MAX) { spin_fail = 1; break; }
-            ekf_poll_sleep();
-        }
-    }
-    {
-        FrBlockRaw raw[PB];
-#pragma unroll
-        for (int j = 0; j < PB; ++j)
-            if (pi[j] >= 0) fr_block_issue(raw[j], ps[j], lane);
-        fr_block_arrive(raw);
-#pragma unroll
-        for (int j = 0; j < PB; ++j) pv[j] = fr_block_value(raw[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < PB; ++j)
-        if (pi[j] >= 0) {
-            pv[j] = fr_block_settle(ps[j], pv[j], lane, spin_fail);
-            fr_block_put(pv[j], colbuf(ptc[j]), kp, nb, pi[j], lane);
-        }
-#pragma unroll
-    for (int j = 0; j < PB; ++j)
-        if (pi[j] >= 0) fr_block_rearm(ps[j], lane);
-    for (int u0 = wave + NW * PB; u0 < ntot; u0 += NW) {
-        int u = u0, tc = 0;
-        while (u >= nb - tc + 1) { u -= nb - tc + 1; ++tc; }
-        const FrBlockSrc s = fr_block_src(fr, nb, tc + u, tc, lane);
-        fr_block_wait(s, spin_fail);
-        fr_block_put(fr_block_take(s, fr_block_load(s, lane), lane, spin_fail), colbuf(tc), kp, nb, tc + u, lane);
-    }
-    __syncthreads();
-    EKF_STAMP();
-
-    // Publication of a finished block column (MFMA operand order, see ekf_kernels.h) by ONE wave
-    // that is not on the pivot chain's critical path, from the LDS copy: 512 contiguous bytes per
-    // store instruction, Dinv last (its last 512 bytes are what the chunks poll).
-    auto publish = [&](int pb) {
-        const double* colb = colbuf(pb);
-        const double* dscr = dscr0 + (pb & 1) * (16 * 17);
-        double dv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dv[r] = dscr[(lane & 15) * 17 + (lane >> 4) + 4 * r];
-        for (int i = pb + 1; i < nb; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                ekf_stc(xlop + sv_lop_index(i, pb) + r * 64 + lane,
-                        -colb[(size_t)(EKF_RB * i + (lane & 15)) * SV_CLD + (lane >> 4) + 4 * r]);
-        if (lane < EKF_RB) ekf_stc(xy + EKF_RB * pb + lane, colb[(size_t)kp * SV_CLD + lane]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            ekf_stc(xdop + (size_t)(pb * 4 + r) * 64 + lane, dv[r]);
-        if (lane == 0) ekf_stc(fr.xl + fr.xl_tag + 1 + pb, fr.seqno);
-        // ring mode: this workgroup reads the column back later (sv_terms_glb): be done before the barrier
-        if (!all_resident) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-    int bad = 0, badb = 0;
-    for (int b = 0; b < nb; ++b) {
-        const int cb = EKF_RB * b;
-        double* cur = colbuf(b);
-        if (b > 0) {
-            for (int i = b + wave; i <= nb; i += NW) {
-                SvAcc a;
-                sv_acc_load(a, cur, kp, i, c, g);
-                sv_term_lds(a, colbuf(b - 1), kp, i, b, c, g);
-                sv_acc_store(a, cur, kp, i, c, g);
-            }
-            __syncthreads();
-        }
-        EKF_STAMP();
-        const int nrows = kp - cb + 1;
-        const int nrw = (nrows > 64) ? (nrows - 64 + 47) / 48 : 0;
-        if (wave <= nrw + 1) {
-            const bool idw = (wave == nrw + 1);
-            int row;
-            if (wave == 0 || lane < EKF_RB) row = cb + lane;
-            else if (idw) row = -1;
-            else row = cb + 64 + 48 * (wave - 1) + (lane - EKF_RB);
-            const bool ident = idw && lane >= EKF_RB && lane < 2 * EKF_RB;
-            const bool live = !idw && (wave == 0 || lane >= EKF_RB) && row <= kp;
-            const double* src = cur + (size_t)min(max(row, 0), kp) * SV_CLD;
-            double a[EKF_RB];
-#pragma unroll
-            for (int x = 0; x < EKF_RB; ++x) a[x] = (row < 0) ? ((x == lane - EKF_RB) ? 1.0 : 0.0) : src[x];
-#pragma unroll
-            for (int j = 0; j < EKF_RB; ++j) {
-                const double d = ekf_readlane_f64(a[j], j);
-                bad |= !(d > 0.0);
-                const double y = ekf_rsqrt_f64(d);
-                const double lj = a[j] * y;
-                a[j] = lj;
-                // broadcasts first, updates second: back-to-back v_readlane into distinct scalar registers,
-                // no wait states between a broadcast and the fma that consumes it
-                double lx[EKF_RB];
-#pragma unroll
-                for (int x = j + 1; x < EKF_RB; ++x) lx[x] = ekf_readlane_f64(lj, x);
-#pragma unroll
-                for (int x = j + 1; x < EKF_RB; ++x) a[x] = __builtin_fma(-lj, lx[x], a[x]);
-            }
-            if (bad && !badb) badb = 100 + b;                                      // diagnostics: first bad block column
-            if (live) {
-                double* dst = cur + (size_t)row * SV_CLD;
-#pragma unroll
-                for (int x = 0; x < EKF_RB; ++x) dst[x] = a[x];
-                if (fr.wdbg && row < kp) {               // dense L for tests only
-#pragma unroll
-                    for (int x = 0; x < EKF_RB; ++x) fr.lmat[(size_t)row * fr.ldl + cb + x] = (cb + x <= row) ? a[x] : 0.0;
-                }
-            }
-            if (ident) {                                 // a[x] = Dinv_b[x][i], i = lane - 16
-                const int i = lane - EKF_RB;
-#pragma unroll
-                for (int x = 0; x < EKF_RB; ++x) dscr0[(b & 1) * (16 * 17) + x * 17 + i] = a[x];
-            }
-        } else {
-            const bool pubonly = NW - (nrw + 2) >= 3;           // wave NW-1 does nothing but publish
-            const int fw = wave - (nrw + 2), nfw = NW - (nrw + 2) - (pubonly ? 1 : 0);
-            if (b > 0 && wave == NW - 1) publish(b - 1);       // off the pivot chain's critical path
-            if (all_resident && b == 0 && nb > 1) {
-                // every remaining block column of S, by all non-pivot waves: they were written together
-                // with block column 0, so no polling (a straggler still reads as a sentinel -> retry path)
-                const int fw0 = wave - (nrw + 2), nfw0 = NW - (nrw + 2);
-                int ntot2 = 0;
-                for (int tc = 1; tc < nb; ++tc) ntot2 += nb - tc + 1;
-                for (int base = fw0; base < ntot2; base += nfw0 * PB) {
-                    sf64x4 v2[PB];
-                    FrBlockSrc s2[PB];
-                    int i2[PB], t2[PB];
-#pragma unroll
-                    for (int j = 0; j < PB; ++j) {
-                        int u = base + nfw0 * j, tc = 1;
-                        const bool has = u < ntot2;
-                        u = has ? u : 0;
-                        while (u >= nb - tc + 1) { u -= nb - tc + 1; ++tc; }
-                        i2[j] = has ? tc + u : -1;
-                        t2[j] = tc;
-                        s2[j] = fr_block_src(fr, nb, tc + u, tc, lane);
-                    }
-                    {
-                        FrBlockRaw raw[PB];
-#pragma unroll
-                        for (int j = 0; j < PB; ++j)
-                            if (i2[j] >= 0) fr_block_issue(raw[j], s2[j], lane);
-                        fr_block_arrive(raw);
-#pragma unroll
-                        for (int j = 0; j < PB; ++j) v2[j] = fr_block_value(raw[j]);
-                    }
-#pragma unroll
-                    for (int j = 0; j < PB; ++j)
-                        if (i2[j] >= 0)
-                            fr_block_put(fr_block_settle(s2[j], v2[j], lane, spin_fail), colbuf(t2[j]), kp, nb, i2[j], lane);
-#pragma unroll
-                    for (int j = 0; j < PB; ++j)
-                        if (i2[j] >= 0) fr_block_rearm(s2[j], lane);
-                }
-            }
-            if (pubonly && wave == NW - 1) {
-                // nothing else
-            } else {
-            if (b >= 1 && b + 1 < nb)
-                for (int i = b + 1 + fw; i <= nb; i += nfw) {
-                    SvAcc a;
-                    sv_acc_load(a, colbuf(b + 1), kp, i, c, g);
-                    sv_term_lds(a, colbuf(b - 1), kp, i, b + 1, c, g);
-                    sv_acc_store(a, colbuf(b + 1), kp, i, c, g);
-                }
-            const int tc = b + 2;
-            if (tc < nb)
-                for (int i = tc + fw; i <= nb; i += nfw) {
-                    if (!all_resident) {
-                        const FrBlockSrc s = fr_block_src(fr, nb, i, tc, lane);
-                        fr_block_wait(s, spin_fail);
-                        fr_block_put(fr_block_take(s, fr_block_load(s, lane), lane, spin_fail), colbuf(tc), kp, nb, i, lane);
-                    }
-                    if (b >= 1) {
-                        SvAcc a;
-                        sv_acc_load(a, colbuf(tc), kp, i, c, g);
-                        int q = 0;
-                        for (; q < b && !(q + RS >= nb || b <= q + RS - 3); ++q) {}
-                        // coherent loads: a chunk on this XCD may have pulled a half-published copy of these lines into the L2
-                        sv_terms_glb<true>(a, xlop, xy, nb, i, tc, q, g, lane);
-                        for (; q < b; ++q) sv_term_lds(a, colbuf(q), kp, i, tc, c, g, (q & 1) != 0);
-                        sv_acc_store(a, colbuf(tc), kp, i, c, g);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        EKF_STAMP();
-    }
-    if (wave == NW - 1) publish(nb - 1);
-    if ((bad | (spin_fail << 2)) && lane == 0) {
-        atomicOr(fr.status, bad | (spin_fail << 2));
-        if (bad) {      // diagnostics: which waves saw it, and the first block column
-            atomicOr(fr.status + 1, 1 << wave);
-            atomicCAS(fr.status + 2, 0, badb);
-        }
-    }
-    EKF_STAMP();
-    if (fr.stamps && tid == 0) fr.stamps[63] = wall_clock64();
-#undef EKF_STAMP
-}
-
-// ---------------------------------------------------------------------------------------------
-// role: one chunk of 64 columns
-// ---------------------------------------------------------------------------------------------
-// right-looking blocked forward substitution on 16 columns, one wave, everything in registers.
-// t[b] starts as A_b and ends as W_b; per finished block column q of the factor:
-//   W_q = Dinv_q t[q] ;  t[i] += (-L_iq) W_q  for i > q ;  dx += W_q^T y_q
-// (same fma sequence per t[i] and for dx as the left-looking stand-alone panel kernel).
-// Only wave 0 of the workgroup polls memory for block column q (4 loads per round, so the
-// factorisation's stores are not stuck behind a storm of polls); the other waves watch an LDS word.
-template <typename T, int NB, int MODEL>
-__device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds, volatile int* sync, double* pshare,
-                                         int wv, int col0, int lane, int& spin_fail) {
-    const int j = lane & 15, g = lane >> 4;
-    const double* __restrict__ xlop = fr.xl;
-    const double* __restrict__ xdop = fr.xl + fr.xl_dop;
-    const double* __restrict__ xy = fr.xl + fr.xl_y;
-    long long* stp = (fr.stamps && col0 == 0 && lane == 0) ? fr.stamps + 34 : nullptr;
-    T* __restrict__ wp = static_cast<T*>(fr.wpanel);
-    pf64x4 t[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) t[b][r] = a_lds[(16 * b + g + 4 * r) * FR_ALD + 16 * wv + j];
-    // the old state of this wave's columns (nobody writes it before the injection below)
-    const int scol = col0 + j;
-    double st_old = 0.0, q_old[4] = {0.0, 0.0, 0.0, 0.0};
-    if (MODEL == 0) {
-        if (scol < fr.dims) st_old = fr.state[scol];
-        if (col0 == 0)
-            for (int i = 0; i < 4; ++i) q_old[i] = fr.state[3 + i];
-    }
-    double part = 0.0;
-#pragma unroll
-    for (int q = 0; q < NB; ++q) {
-        double dq[4], yq[4];
-        if (wv == 0) {
-            // sync[0] = block columns shared so far, sync[1] = reads of the shared slot acknowledged
-            int it = 0;
-            if (q < NB - 1)      // (the last block column is polled on the data itself: one round trip less)
-                while (ekf_is_sent(ekf_ldc(xdop + (size_t)(q * 4 + 3) * 64 + 63))) {      // the word written last
-                    if (++it > EKF_SPIN_MAX) { spin_fail = 1; break; }
-                    ekf_poll_sleep();
-                }
-            for (it = 0;; ++it) {
-                bool pend = false;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    dq[r] = ekf_ldt(xdop + (size_t)(q * 4 + r) * 64 + lane, it > 0 || q == NB - 1);
-                    yq[r] = ekf_ldt(xy + 16 * q + g + 4 * r, it > 0 || q == NB - 1);
-                    pend = pend || ekf_is_sent(dq[r]) || ekf_is_sent(yq[r]);
-                }
-                if (!__any(pend)) break;
-                if (it > EKF_SPIN_MAX) { spin_fail = 1; break; }
-                ekf_poll_sleep();
-            }
-            it = 0;
-            while (sync[1] < 3 * q) {                  // the slot's previous content has been read
-                if (++it > 64 * EKF_SPIN_MAX) { spin_fail = 1; break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                pshare[r * 64 + lane] = dq[r];
-                pshare[(4 + r) * 64 + lane] = yq[r];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the slot before the word that announces it
-            if (lane == 0) sync[0] = q + 1;
-        } else {
-            int it = 0;
-            while (sync[0] < q + 1) {
-                if (++it > 64 * EKF_SPIN_MAX) { spin_fail = 1; break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                dq[r] = pshare[r * 64 + lane];
-                yq[r] = pshare[(4 + r) * 64 + lane];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the reads before the acknowledgement
-            if (lane == 0) atomicAdd(const_cast<int*>(sync) + 1, 1);
-        }
-        if (wv == 0 && lane == 0) {
-            const double tag = ekf_ldc(fr.xl + fr.xl_tag + 1 + q);
-            if (!ekf_is_sent(tag) && tag != fr.seqno) atomicOr(fr.status, 32);
-        }
-        pf64x4 wq = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) wq = __builtin_amdgcn_mfma_f64_16x16x4f64(dq[r], t[q][r], wq, 0, 0, 0);
-        t[q] = wq;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {                   // W rows of block q are final
-            const int row = 16 * q + g + 4 * r;
-            wp[(int64_t)row * fr.ldw + col0 + j] = (T)wq[r];
-            if (fr.wdbg) fr.wdbg[(int64_t)row * fr.ldw + col0 + j] = wq[r];
-        }
-        // t[i] += (-L_iq) W_q for i > q, at most LG blocks of -L in registers at a time (the whole
-        // kernel has to stay clear of register spills)
-        constexpr int LG = 6;
-#pragma unroll
-        for (int i0 = q + 1; i0 < NB; i0 += LG) {
-            double lq[LG][4];
-            int it = 0;
-            for (;;) {      // normally one pass: the -L blocks of column q were published before Dinv
-                bool pend = false;
-#pragma unroll
-                for (int i = i0; i < NB && i < i0 + LG; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        lq[i - i0][r] = ekf_ldt(xlop + sv_lop_index(i, q) + r * 64 + lane, it > 0);
-                        pend = pend || ekf_is_sent(lq[i - i0][r]);
-                    }
-                if (!__any(pend)) break;
-                if (++it > EKF_SPIN_MAX) { spin_fail = 1; break; }
-                ekf_poll_sleep();
-            }
-#pragma unroll
-            for (int i = i0; i < NB && i < i0 + LG; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    t[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(lq[i - i0][r], wq[r], t[i], 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) part = __builtin_fma(wq[r], yq[r], part);
-        if (stp) stp[q] = wall_clock64();
-    }
-    part += __shfl_xor(part, 16);
-    part += __shfl_xor(part, 32);                    // dx[col0 + j] in every lane group
-    const int col = col0 + j;
-    if (MODEL == 1) {               // every landmark has a quaternion: injected by the last chunk
-        if (g == 0) ekf_stc(fr.dxvec + col, part);
-    } else {
-        // extended_kalman_filter.py:133-152.  Nobody reads the state any more: its only readers
-        // in this launch are the S-block workgroups, which the factorisation has waited for.
-        double nv = 0.0;
-        if (g == 0 && (col < 3 || (col >= EKF_CAM && col < fr.dims))) {
-            nv = st_old + part;
-            fr.state[col] = nv;
-        }
-        if (col0 == 0) {
-            const double e0 = __shfl(part, 7), e1 = __shfl(part, 8), e2 = __shfl(part, 9);
-            const double x0 = __shfl(nv, 0), x1 = __shfl(nv, 1), x2 = __shfl(nv, 2);
-            if (lane == 0) {
-                double qv[4] = {q_old[0], q_old[1], q_old[2], q_old[3]};
-                const double err[3] = {e0, e1, e2};
-                ekf_quat_inject(qv, err, fr.quat_mode);
-                for (int i = 0; i < 4; ++i) fr.state[3 + i] = qv[i];
-                for (int i = 0; i < 3; ++i) fr.state[7 + i] = 0.0;   // :152
-                if (fr.traj_row) {
-                    fr.traj_row[0] = x0; fr.traj_row[1] = x1; fr.traj_row[2] = x2;
-                    for (int i = 0; i < 4; ++i) fr.traj_row[3 + i] = qv[i];
-                }
-            }
-        }
-    }
-    if (stp) stp[NB] = wall_clock64();
-}
-
-template <typename T, int NU, int MODEL, int NB>
-__device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, double* sm) {
-    constexpr int RD = EkfModel<MODEL>::RD, LMD = EkfModel<MODEL>::LMD, JC = EkfModel<MODEL>::JC;
-    constexpr int NWV = FR_T / 64;
-    double* hs = sm;                                    // [k][JC]
-    double* a_lds = sm + fr.k * JC;                     // [kpad][FR_ALD]
-    int* lmc = reinterpret_cast<int*>(a_lds + (size_t)fr.kpad * FR_ALD);
-    int* flag = lmc + 64;                               // [0] last-chunk flag, [1..2] panel sync words
-    double* pshare = reinterpret_cast<double*>(lmc + 72);   // [8][64] Dinv operands and y of one block column
-    const int tid = threadIdx.x, m = fr.m;
-    const int chunk0 = chunk * 64, cl = tid & 63, c = chunk0 + cl, g = tid >> 6;
-    const T* __restrict__ P = static_cast<const T*>(fr.cov);
-    const T* __restrict__ prow = static_cast<const T*>(fr.prow);
-    const int64_t ld = fr.ld;
-    if (fr.stamps && chunk == 0 && tid == 0) fr.stamps[32] = wall_clock64();
-    T pcr[EKF_CAM];
-#pragma unroll
-    for (int a = 0; a < EKF_CAM; ++a) pcr[a] = prow ? prow[(int64_t)a * fr.ldw + c] : P[a * ld + c];
-    if (tid < m) lmc[tid] = EKF_CAM + LMD * fr.idx[tid];
-    if (tid == 0) { flag[1] = 0; flag[2] = 0; }
-    __syncthreads();
-    T plr[NU][LMD];
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        const int ju = min(g + NWV * u, m - 1);
-        const int c0 = lmc[ju];
-#pragma unroll
-        for (int d = 0; d < LMD; ++d)
-            plr[u][d] = prow ? prow[(int64_t)(EKF_CAM + LMD * ju + d) * fr.ldw + c] : P[(int64_t)(c0 + d) * ld + c];
-    }
-    // Jacobian rows: published by S-block workgroup 0 (this role never reads the state, so the
-    // injection at the end of the launch cannot race with a chunk that starts late)
-    {
-        const double* __restrict__ xj = fr.xl + fr.xl_jac;
-        const int nel = fr.k * JC;
-        int spin = 0;
-        if (tid < 64) {        // one wave polls one word (the last one written)
-            int it = 0;
-            while (ekf_is_sent(ekf_ldc(xj + nel - 1))) {
-                if (++it > EKF_SPIN_MAX) { spin = 1; break; }
-                ekf_poll_sleep();
-            }
-        }
-        __syncthreads();
-        for (int e = tid; e < nel; e += FR_T) {
-            double v = ekf_ldt(xj + e, false);
-            int it = 0;
-            while (ekf_is_sent(v)) {
-                if (++it > EKF_SPIN_MAX) { spin = 1; break; }
-                ekf_poll_sleep();
-                v = ekf_ldc(xj + e);
-            }
-            hs[e] = v;
-        }
-        if (spin) atomicOr(fr.status, 4);
-        if (tid == 0) {
-            const double tag = ekf_ldc(fr.xl + fr.xl_tag);
-            if (!ekf_is_sent(tag) && tag != fr.seqno) atomicOr(fr.status, 16);
-        }
-    }
-    __syncthreads();
-    double pc[EKF_CAM];
-#pragma unroll
-    for (int a = 0; a < EKF_CAM; ++a) pc[a] = (double)pcr[a] + ((a == c) ? ekf_qdiag(a, fr.dims, fr.nz) : 0.0);
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        const int j = g + NWV * u;
-        if (j < m) {
-            const int c0 = lmc[j];
-            double pl[LMD];
-#pragma unroll
-            for (int d = 0; d < LMD; ++d) pl[d] = (double)plr[u][d] + ((c0 + d == c) ? fr.nz.q_lm : 0.0);
-#pragma unroll
-            for (int d = 0; d < RD; ++d) {
-                const int r = RD * j + d;
-                const double* hr = hs + r * JC;
-                double acc = 0.0;
-#pragma unroll
-                for (int a = 0; a < EKF_CAM; ++a) acc = __builtin_fma(hr[a], pc[a], acc);
-#pragma unroll
-                for (int e = 0; e < LMD; ++e) acc = __builtin_fma(hr[10 + e], pl[e], acc);
-                a_lds[r * FR_ALD + cl] = acc;
-                if (fr.wdbg) fr.amat[(int64_t)r * fr.lda + c] = acc;
-            }
-        }
-    }
-    for (int r = fr.k + g; r < fr.kpad; r += NWV) a_lds[r * FR_ALD + cl] = 0.0;
-    __syncthreads();
-    if (fr.stamps && chunk == 0 && tid == 0) fr.stamps[33] = wall_clock64();
-    int spin_fail = 0;
-    if (g < 4) {
-        const int lane = tid & 63, col0 = chunk0 + 16 * g;
-        fr_panel<T, NB, MODEL>(fr, a_lds, flag + 1, pshare, g, col0, lane, spin_fail);
-        if (spin_fail && (tid & 63) == 0) atomicOr(fr.status, 4);
-    }
-    if (MODEL == 0) return;
-    // ---- EKF_Rotations: dx of this chunk has to be in memory before the chunk counts as done;
-    // the last chunk injects (ekf_with_rotations.py:142-177): camera and every landmark: xyz
-    // additive, quaternion multiplicative (scalar first); landmark error states are never written
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned long long old =
-            __hip_atomic_fetch_add(fr.done_ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        flag[0] = (old + 1 == fr.done_target);
-    }
-    __syncthreads();
-    if (!flag[0]) return;
-    for (int i = tid; i <= fr.n_lm; i += FR_T) {
-        const int c0 = (i == 0) ? 0 : EKF_CAM + 10 * (i - 1);
-        double* st = fr.state + c0;
-        const double* dx = fr.dxvec + c0;
-        double q[4] = {st[3], st[4], st[5], st[6]};
-        const double err[3] = {ekf_ldc(dx + 7), ekf_ldc(dx + 8), ekf_ldc(dx + 9)};
-        ekf_quat_inject(q, err, 1);
-        const double x0 = st[0] + ekf_ldc(dx + 0), x1 = st[1] + ekf_ldc(dx + 1), x2 = st[2] + ekf_ldc(dx + 2);
-        st[0] = x0; st[1] = x1; st[2] = x2;
-        for (int e = 0; e < 4; ++e) st[3 + e] = q[e];
-        if (i == 0) {
-            for (int e = 0; e < 3; ++e) st[7 + e] = 0.0;
-            if (fr.traj_row) {
-                fr.traj_row[0] = x0; fr.traj_row[1] = x1; fr.traj_row[2] = x2;
-                for (int e = 0; e < 4; ++e) fr.traj_row[3 + e] = q[e];
-            }
-        }
-    }
-}
-
-// One instantiation per number of 16-row blocks NB = kpad / 16: the forward substitution is unrolled
-// over NB, and a kernel that carried all twelve variants spilled registers.
-template <typename T, int NU, int MODEL, int NB>
-__global__ __launch_bounds__(FR_T) void ekf_front_kernel(EkfFrame fr, int RS) {
-    extern __shared__ __attribute__((aligned(16))) double fr_sm[];
-    const int nb = fr.kpad / EKF_RB, nS = nb * (nb + 1) / 2;
-    const int bx = blockIdx.x;
-    if (bx == 0) fr_role_measure<MODEL>(fr, fr_sm);
-    else if (bx <= nS) fr_role_sblock<T, MODEL>(fr, bx - 1, nS, fr_sm);
-    else if (bx == nS + 1) fr_role_factor(fr, RS, fr_sm);
-    else fr_role_chunk<T, NU, MODEL, NB>(fr, bx - nS - 2, fr_sm);
-}
-
-template <typename T, int NU, int MODEL, int NB>
-static void ekf_front_go(const EkfFrame& fr, hipStream_t s) {
-    constexpr int LMD = EkfModel<MODEL>::LMD, JC = EkfModel<MODEL>::JC;
-    constexpr int NSLOT = EKF_CAM + LMD * EkfModel<MODEL>::NDET16;
-    static bool once = false;
-    if (!once) {   // > 64 KB of dynamic LDS needs the opt-in
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ekf_front_kernel<T, NU, MODEL, NB>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        once = true;
-    }
-    const int nb = fr.kpad / EKF_RB, nS = nb * (nb + 1) / 2;
-    const size_t lds_s = ((size_t)fr.k * JC + NSLOT * 16 + 32 + fr.kpad) * 8 + 16;
-    const size_t lds_c = ((size_t)fr.k * JC + (size_t)fr.kpad * FR_ALD) * 8 + 72 * 4 + 8 * 64 * 8 + 16;
-    const size_t lds_f = (size_t)ekf_solve_stream_lds_bytes(fr.kpad, fr.k) + 2 * 16 * 17 * 8;
-    size_t lds = lds_s > lds_c ? lds_s : lds_c;
-    if (lds_f > lds) lds = lds_f;
-    hipLaunchKernelGGL((ekf_front_kernel<T, NU, MODEL, NB>), dim3(nS + 2 + fr.ncols / 64), dim3(FR_T), lds, s, fr,
-                       ekf_solve_stream_ring(fr.kpad, fr.k));
-}
-
-template <typename T>
-void ekf_launch_front(const EkfFrame& fr, hipStream_t s) {
-    const int nb = fr.kpad / EKF_RB;
-#define FR_GO(NU, MODEL, NB) case NB: return ekf_front_go<T, NU, MODEL, NB>(fr, s);
-    if (fr.model == 1) {                 // EKF_Rotations: m <= 27, k = 7 m
-        switch (nb) {
-            FR_GO(4, 1, 1) FR_GO(4, 1, 2) FR_GO(4, 1, 3) FR_GO(4, 1, 4) FR_GO(4, 1, 5) FR_GO(4, 1, 6)
-            FR_GO(4, 1, 7) FR_GO(4, 1, 8) FR_GO(4, 1, 9) FR_GO(4, 1, 10) FR_GO(4, 1, 11)
-            default: return ekf_front_go<T, 4, 1, 12>(fr, s);
-        }
-    }
-    if (fr.m <= 32) {                    // k = 3 m <= 96
-        switch (nb) {
-            FR_GO(4, 0, 1) FR_GO(4, 0, 2) FR_GO(4, 0, 3) FR_GO(4, 0, 4) FR_GO(4, 0, 5)
-            default: return ekf_front_go<T, 4, 0, 6>(fr, s);
-        }
-    }
-    switch (nb) {                        // m = 33 .. 64: k = 99 .. 192
-        FR_GO(8, 0, 7) FR_GO(8, 0, 8) FR_GO(8, 0, 9) FR_GO(8, 0, 10) FR_GO(8, 0, 11)
-        default: return ekf_front_go<T, 8, 0, 12>(fr, s);
-    }
-#undef FR_GO
-}
 template void ekf_launch_front<float>(const EkfFrame&, hipStream_t);
-template void ekf_launch_front<double>(const EkfFrame&, hipStream_t);

@@ -52,7 +52,7 @@ struct EkfFrame {
     const void* prow;          // read by the gather kernel; null = read P
     EkfNoise nz;
     int32_t quat_mode;
-    // fused front kernel (ekf_front.hip): exchange buffers between its workgroups
+    // fused front kernel (ekf_front_impl.h): exchange buffers between its workgroups
     double* xs;                // S blocks, layout of sblk; sentinel-armed, re-armed by the consumer
     double* xr;                // [kmax] z - h (0 for rows k..kpad-1)
     double* xl;                // this frame's exchange: [-L operands | Dinv operands | y | Jacobian rows [k][JC]]
@@ -66,7 +66,7 @@ struct EkfFrame {
     double seqno;                      // this frame's tag
 };
 
-// fused gather + solve + panel (+ injection); see ekf_front.hip
+// fused gather + solve + panel (+ injection); see ekf_front_impl.h
 template <typename T> void ekf_launch_front(const EkfFrame& fr, hipStream_t s);
 int ekf_solve_stream_ring(int kpad, int k);
 int ekf_solve_stream_lds_bytes(int kpad, int k);

@@ -1,5 +1,5 @@
 // Device helpers of the blocked Cholesky shared by the stand-alone solve kernel
-// (ekf_small_kernels.hip) and the fused front kernel (ekf_front.hip).  gfx950 only.
+// (ekf_small_kernels.hip) and the fused front kernel (ekf_front_impl.h).  gfx950 only.
 #pragma once
 #include "ekf_kernels.h"
 

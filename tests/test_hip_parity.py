@@ -542,7 +542,7 @@ def test_checkpoint_resume_is_bitwise(tmp_path, make, dtype):
 
 
 # ---------------------------------------------------------------------------
-# fused front kernel (ekf_front.hip) vs the three separate launches (cfg.flags bit 2)
+# fused front kernel (ekf_front_impl.h) vs the three separate launches (cfg.flags bit 2)
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("make,n,m,dtype", [(_ekf, 24, 8, "float64"), (_ekf, 24, 8, "float32"),
                                             (_ekf, 256, 16, "float64"), (_ekf, 1024, 32, "float32"),
