@@ -139,6 +139,7 @@ struct ekf_filter {
     size_t slot_bytes = 0;
     int slot = 0;
     hipEvent_t slot_done[kStageSlots] = {};
+    char* readback = nullptr;           // pinned: [status words (256 B) | state (cap doubles)], one sync per getter
     // kernel timing
     bool timing = false;
     bool timing_cov_only = false;
@@ -286,10 +287,14 @@ int check_ready(ekf_filter* f) {
     return EKF_OK;
 }
 
-int sync_and_check(ekf_filter* f) {
+// `state_count` > 0: the first state_count doubles of the state come back with the same synchronisation
+// (f->readback + 256): one stream sync per getter instead of a sync and two blocking copies
+int sync_and_check(ekf_filter* f, int state_count = 0) {
+    HIP_TRY(hipMemcpyAsync(f->readback, f->at<int32_t>(f->lay.off_status), 32, hipMemcpyDeviceToHost, f->stream));
+    if (state_count > 0)
+        HIP_TRY(hipMemcpyAsync(f->readback + 256, f->state, (size_t)state_count * 8, hipMemcpyDeviceToHost, f->stream));
     HIP_TRY(hipStreamSynchronize(f->stream));
-    int32_t st = 0;
-    HIP_TRY(hipMemcpy(&st, f->at<int32_t>(f->lay.off_status), sizeof(st), hipMemcpyDeviceToHost));
+    const int32_t st = reinterpret_cast<const int32_t*>(f->readback)[0];
     static const bool ignore = getenv("EKF_IGNORE_NUMERIC") != nullptr;   // timing ablations only
     if (st != 0 && !ignore) {
         if (st & (16 | 32))   // diagnostics: a chunk accepted exchange data that carries another frame's tag
@@ -298,8 +303,7 @@ int sync_and_check(ekf_filter* f) {
         if (st & 4)   // a bounded wait inside the fused front kernel ran out (should never happen)
             return fail(EKF_ERR_NUMERIC, "internal: exchange wait timed out in the front kernel (status " +
                                              std::to_string(st) + ")");
-        int32_t info[8] = {};
-        (void)hipMemcpy(info, f->at<int32_t>(f->lay.off_status), sizeof(info), hipMemcpyDeviceToHost);
+        const int32_t* info = reinterpret_cast<const int32_t*>(f->readback);
         return fail(EKF_ERR_NUMERIC, "innovation covariance S was not positive definite (block column " +
                                          std::to_string(info[2] - 100) + ", wave mask " + std::to_string(info[1]) + ")");
     }
@@ -363,6 +367,11 @@ int ekf_create(const ekf_config* cfg, ekf_filter** out) {
         delete f;
         return fail(EKF_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
     }
+    e = hipHostMalloc(reinterpret_cast<void**>(&f->readback), 256 + (size_t)f->lay.cap * 8, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        ekf_destroy(f);
+        return fail(EKF_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    }
     e = hipStreamCreateWithFlags(&f->big, hipStreamNonBlocking);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
         e = hipEventCreateWithFlags(&f->ev_small[i], hipEventDisableTiming);
@@ -398,6 +407,7 @@ int ekf_destroy(ekf_filter* f) {
     for (int i = 0; i < kStageSlots; ++i)
         if (f->slot_done[i]) (void)hipEventDestroy(f->slot_done[i]);
     if (f->pinned) (void)hipHostFree(f->pinned);
+    if (f->readback) (void)hipHostFree(f->readback);
     delete f;
     return EKF_OK;
 }
@@ -521,9 +531,10 @@ int ekf_observe(ekf_filter* f, const int32_t* lm_index, const double* z, int32_t
     const size_t zb = (size_t)m * L.rd * 8;
     std::memcpy(hidx, lm_index, (size_t)m * 4);
     std::memcpy(hz, z, zb);
-    HIP_TRY(hipMemcpyAsync(f->at<int32_t>(L.off_idx), hidx, (size_t)m * 4, hipMemcpyHostToDevice,
-                           f->stream));
-    HIP_TRY(hipMemcpyAsync(f->at<double>(L.off_z), hz, zb, hipMemcpyHostToDevice, f->stream));
+    // one copy: the pinned slot mirrors the device staging layout [indices, padded to 256 B | z]
+    static_assert(sizeof(int32_t) == 4, "layout");
+    if (L.off_z - L.off_idx != align256((size_t)f->cfg.max_visible * 4)) return fail(EKF_ERR_STATE, "staging layout");
+    HIP_TRY(hipMemcpyAsync(f->at<char>(L.off_idx), slot, (L.off_z - L.off_idx) + zb, hipMemcpyHostToDevice, f->stream));
     rc = enqueue_frame(f, f->at<int32_t>(L.off_idx), f->at<double>(L.off_z), m, nullptr);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(f->slot_done[f->slot], f->stream));
@@ -616,9 +627,9 @@ int ekf_get_state(ekf_filter* f, double* out, int32_t count) {
     int rc = check_ready(f);
     if (rc) return rc;
     if (!out || count < 0 || count > f->dims()) return fail(EKF_ERR_INVALID, "bad state request");
-    rc = sync_and_check(f);
+    rc = sync_and_check(f, count);
     if (rc) return rc;
-    HIP_TRY(hipMemcpy(out, f->state, (size_t)count * 8, hipMemcpyDeviceToHost));
+    std::memcpy(out, f->readback + 256, (size_t)count * 8);
     return EKF_OK;
 }
 
