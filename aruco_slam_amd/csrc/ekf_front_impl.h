@@ -52,11 +52,11 @@ __device__ __forceinline__ void fr_measure(const EkfFrame& fr, const double* cam
     constexpr int RD = EkfModel<MODEL>::RD, LMD = EkfModel<MODEL>::LMD, JC = EkfModel<MODEL>::JC;
     if (tid < fr.m) {
         const int c0 = lmc[tid];
-        double lm[LMD], h[RD], J[RD][JC];
+        double lm[LMD], h[RD];
         for (int d = 0; d < LMD; ++d) lm[d] = fr.state[c0 + d];
+        // the Jacobian rows are built in place in LDS (7 x 20 doubles would not fit the registers)
+        double (*J)[JC] = reinterpret_cast<double (*)[JC]>(hs + (size_t)RD * tid * JC);
         ekf_measure_model<MODEL>(cam, lm, h, J);
-        for (int d = 0; d < RD; ++d)
-            for (int a = 0; a < JC; ++a) hs[(RD * tid + d) * JC + a] = J[d][a];
         if (publish) {
             for (int d = 0; d < RD; ++d) {
                 for (int a = 0; a < JC; ++a) fr.jac[(size_t)(RD * tid + d) * EKF_JLD + a] = J[d][a];
