@@ -663,7 +663,7 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
         }
         // t[i] += (-L_iq) W_q for i > q, at most LG blocks of -L in registers at a time (the whole
         // kernel has to stay clear of register spills)
-        constexpr int LG = 6;
+        constexpr int LG = (NB >= 11) ? 4 : 6;
 #pragma unroll
         for (int i0 = q + 1; i0 < NB; i0 += LG) {
             double lq[LG][4];
