@@ -43,8 +43,9 @@ struct Layout {
     size_t elem;      // sizeof(cov element)
     size_t off_jac, off_resid, off_y, off_lmcol, off_amat, off_sblk, off_lmat, off_dinv, off_lop, off_dop, off_wpanel, off_wpanel2, off_prow, off_wdbg,
         off_idx, off_z, off_status, off_stamps, off_dx, off_diag, off_xyz, off_unc,
-        off_xs, off_xr, off_xl, off_done, total;
-    size_t xs_len, xl_len, xl_dop, xl_y, xl_jac, xl_tag;   // fused front kernel exchange buffers (doubles)
+        off_xl, off_done, total;
+    // fused front kernel: one exchange buffer per fused-frame parity (offsets / length in doubles)
+    size_t xl_len, xl_dop, xl_y, xl_jac, xl_tag, xl_xs, xl_xr, xl_stag;
 };
 
 Layout make_layout(const ekf_config& c) {
@@ -83,14 +84,14 @@ Layout make_layout(const ekf_config& c) {
     L.off_unc = take((size_t)256 * 10 * 8);
     {
         const size_t nb = (size_t)L.kmax / EKF_RB;
-        L.xs_len = nb * L.kmax * 16;
         L.xl_dop = nb * (nb - 1) / 2 * 256 + 64;
         L.xl_y = L.xl_dop + nb * 256;
         L.xl_jac = L.xl_y + L.kmax;
         L.xl_tag = L.xl_jac + (size_t)L.kmax * EKF_JLD;
-        L.xl_len = L.xl_tag + 32;
-        L.off_xs = take(L.xs_len * 8);
-        L.off_xr = take((size_t)L.kmax * 8);
+        L.xl_xs = L.xl_tag + 32;                          // S blocks, layout of sblk ([block column][kmax][16])
+        L.xl_xr = L.xl_xs + nb * L.kmax * 16;             // residual
+        L.xl_stag = L.xl_xr + (size_t)round_up(L.kmax, 16);   // S-block tags [16 tc + i]
+        L.xl_len = L.xl_stag + 256;
         L.off_xl = take(2 * L.xl_len * 8);
         L.off_done = take(256);
     }
@@ -132,8 +133,8 @@ struct ekf_filter {
     int n_lm = 0;
     int last_m = 0;
     bool debug_w = false;
-    uint64_t seq = 0;          // frames enqueued since reset (parity of the factor exchange buffer)
-    uint64_t done_total = 0;   // column chunks enqueued since reset (fused front kernel)
+    uint64_t fseq = 0;         // FUSED frames enqueued since reset: parity of the exchange buffer, frame tag
+    uint64_t done_total = 0;   // column chunks of fused frames enqueued since reset
     // pinned staging ring for host-pointer observes
     char* pinned = nullptr;
     size_t slot_bytes = 0;
@@ -207,35 +208,35 @@ EkfFrame make_frame(ekf_filter* f, const int32_t* idx_dev, const double* z_dev, 
     fr.stamps = f->debug_w ? f->at<long long>(L.off_stamps) : nullptr;
     fr.nz = EkfNoise{f->cfg.q_cam, f->cfg.q_err, f->cfg.q_lm, f->cfg.r_uncertainty};
     fr.quat_mode = f->cfg.quat_mode;
-    fr.xs = f->at<double>(L.off_xs);
-    fr.xr = f->at<double>(L.off_xr);
-    fr.xl = f->at<double>(L.off_xl) + (f->seq & 1) * L.xl_len;
-    fr.xl_next = f->at<double>(L.off_xl) + ((f->seq + 1) & 1) * L.xl_len;
+    fr.n_lm = f->n_lm;
+    return fr;
+}
+
+// Fused front kernel or the three stage kernels?  Fused unless the caller opted out (flags bit 2).
+bool use_front_kernel(const ekf_filter* f, const EkfFrame&) { return (f->cfg.flags & 4) == 0; }
+
+// Exchange buffers of a FUSED frame.  Parity, frame tag and the chunk counter advance with the fused
+// frames only: a stage-kernel frame neither uses nor re-arms the exchange, so a filter may alternate
+// between the two paths (flags can differ per handle, not per frame, today -- but the bookkeeping does
+// not depend on that).
+void bind_exchange(ekf_filter* f, EkfFrame& fr) {
+    const Layout& L = f->lay;
+    double* base = f->at<double>(L.off_xl);
+    fr.xl = base + (f->fseq & 1) * L.xl_len;
+    fr.xl_next = base + ((f->fseq + 1) & 1) * L.xl_len;
     fr.xl_dop = (int32_t)L.xl_dop;
     fr.xl_y = (int32_t)L.xl_y;
     fr.xl_jac = (int32_t)L.xl_jac;
     fr.xl_tag = (int32_t)L.xl_tag;
-    fr.seqno = (double)(f->seq + 1);
     fr.xl_len = (int32_t)L.xl_len;
-    fr.n_lm = f->n_lm;
+    fr.xs = fr.xl + L.xl_xs;
+    fr.xr = fr.xl + L.xl_xr;
+    fr.xs_tag = fr.xl + L.xl_stag;
+    fr.seqno = (double)(f->fseq + 1);
     fr.done_ctr = f->at<unsigned long long>(L.off_done);
     f->done_total += (uint64_t)(fr.ncols / 64);
     fr.done_target = f->done_total;
-    f->seq++;
-    return fr;
-}
-
-// Fused front kernel or the three stage kernels?  The fused kernel is used unless the caller opted out
-// (flags bit 2) or the frame is in the one regime where it is not trusted yet: k > 128 together with
-// (almost) more workgroups than CUs -- there, roughly one frame in a thousand of a long back-to-back
-// sequence came out with a garbage S block (n >= 3700, m = 64; never with a host sync every other
-// frame, never for k <= 144 or fewer than 222 workgroups; cause not found).
-// The stage kernels are equally fast at those sizes.  flags bit 3 forces the fused kernel (diagnostics).
-bool use_front_kernel(const ekf_filter* f, const EkfFrame& fr) {
-    if (f->cfg.flags & 4) return false;
-    if (f->cfg.flags & 8) return true;
-    const int nb = fr.kpad / EKF_RB, grid = nb * (nb + 1) / 2 + 2 + fr.ncols / 64;
-    return fr.kpad <= 128 || grid <= 200;
+    f->fseq++;
 }
 
 // predict + update for one frame: the front kernel (or gather / solve / panel) and the covariance update
@@ -257,6 +258,7 @@ int enqueue_frame(ekf_filter* f, const int32_t* idx_dev, const double* z_dev, in
     if (ev_all) HIP_TRY(hipEventRecord(ev[0], f->stream));
     if (use_front_kernel(f, fr)) {
         // one launch: timing slot 0 = the whole front kernel, slots 1 and 2 stay empty
+        bind_exchange(f, fr);
         if (f32) ekf_launch_front<float>(fr, f->stream); else ekf_launch_front<double>(fr, f->stream);
         if (ev_all) {
             HIP_TRY(hipEventRecord(ev[1], f->stream));
@@ -297,10 +299,14 @@ int sync_and_check(ekf_filter* f, int state_count = 0) {
     const int32_t st = reinterpret_cast<const int32_t*>(f->readback)[0];
     static const bool ignore = getenv("EKF_IGNORE_NUMERIC") != nullptr;   // timing ablations only
     if (st != 0 && !ignore) {
-        if (st & (16 | 32))   // diagnostics: a chunk accepted exchange data that carries another frame's tag
-            return fail(EKF_ERR_NUMERIC, "internal: stale exchange data accepted in the front kernel (status " +
+        // (sticky until ekf_reset: after any of these the filter state is not trustworthy)
+        if (st & EKF_ST_BAD_INDEX)
+            return fail(EKF_ERR_INVALID, "landmark index out of range in a device-resident detection array "
+                                         "(clamped on the device; the filter state is no longer meaningful, reset it)");
+        if (st & (EKF_ST_STALE_JAC | EKF_ST_STALE_COL | EKF_ST_STALE_S))
+            return fail(EKF_ERR_NUMERIC, "internal: exchange data of another frame accepted in the front kernel (status " +
                                              std::to_string(st) + ")");
-        if (st & 4)   // a bounded wait inside the fused front kernel ran out (should never happen)
+        if (st & EKF_ST_TIMEOUT)   // a bounded wait inside the fused front kernel ran out (should never happen)
             return fail(EKF_ERR_NUMERIC, "internal: exchange wait timed out in the front kernel (status " +
                                              std::to_string(st) + ")");
         const int32_t* info = reinterpret_cast<const int32_t*>(f->readback);
@@ -441,13 +447,9 @@ int ekf_reset(ekf_filter* f, const double initial_camera_pose[10]) {
     HIP_TRY(hipMemsetAsync(f->state, 0, (size_t)L.cap * 8, f->stream));
     HIP_TRY(hipMemsetAsync(f->ws, 0, L.total, f->stream));
     // arm the exchange buffers of the fused front kernel (ekf_solve_device.h: EKF_SENT_BITS)
-    HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(f->at<char>(L.off_xs)), (int)0xFFFBADC0u,
-                              L.xs_len * 2, f->stream));
-    HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(f->at<char>(L.off_xr)), (int)0xFFFBADC0u,
-                              (size_t)L.kmax * 2, f->stream));
     HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(f->at<char>(L.off_xl)), (int)0xFFFBADC0u,
                               L.xl_len * 4, f->stream));
-    f->seq = 0;
+    f->fseq = 0;
     f->done_total = 0;
     HIP_TRY(hipMemcpyAsync(f->state, initial_camera_pose, 10 * sizeof(double), hipMemcpyHostToDevice,
                            f->stream));
@@ -548,6 +550,8 @@ int ekf_observe_device(ekf_filter* f, const int32_t* lm_index_dev, const double*
     if (m < 1) return fail(EKF_ERR_INVALID, "observe needs at least one detection");
     if (m > f->cfg.max_visible) return fail(EKF_ERR_CAPACITY, "more detections than max_visible");
     if (!lm_index_dev || !z_dev) return fail(EKF_ERR_INVALID, "NULL detections");
+    if (f->n_lm < 1) return fail(EKF_ERR_STATE, "observe before any landmark was added");
+    // the indices are device-resident: range-checked by the kernels (EKF_ERR_INVALID at the next sync)
     return enqueue_frame(f, lm_index_dev, z_dev, m, nullptr);
 }
 
@@ -558,6 +562,7 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
     if (m < 1 || frames < 0) return fail(EKF_ERR_INVALID, "bad sequence shape");
     if (m > f->cfg.max_visible) return fail(EKF_ERR_CAPACITY, "more detections than max_visible");
     if (!lm_index_dev || !z_dev) return fail(EKF_ERR_INVALID, "NULL detections");
+    if (f->n_lm < 1) return fail(EKF_ERR_STATE, "observe before any landmark was added");
     // opt-in only: every cross-stream event costs a few us of bubble and the two streams compete for
     // the CUs; measured slower than the serial order at every size since the front kernel is fused
     // (n=1024: 17.6k vs 19.0k updates/s, n=4096: 1.69k vs 1.90k)
@@ -586,6 +591,7 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
         fr.wpanel = wbuf[par];
         fr.prow = (t > 0) ? prow : nullptr;
         if (use_front_kernel(f, fr)) {
+            bind_exchange(f, fr);
             if (f32) ekf_launch_front<float>(fr, f->stream); else ekf_launch_front<double>(fr, f->stream);
         } else {
             if (f32) ekf_launch_gather<float>(fr, f->stream); else ekf_launch_gather<double>(fr, f->stream);
@@ -707,6 +713,12 @@ int ekf_set_cov(ekf_filter* f, const double* cov, int32_t dims) {
         HIP_TRY(hipMemcpy2D(f->cov, (size_t)f->ld * 4, tmp.data(), (size_t)dims * 4, (size_t)dims * 4,
                             dims, hipMemcpyHostToDevice));
     }
+    return EKF_OK;
+}
+
+int ekf_set_fused(ekf_filter* f, int32_t enable) {
+    if (!f) return fail(EKF_ERR_INVALID, "filter handle is NULL");
+    if (enable) f->cfg.flags &= ~4; else f->cfg.flags |= 4;
     return EKF_OK;
 }
 

@@ -16,15 +16,18 @@
 //  * MFMA kernels: one wavefront per 32x32 tile of the LOWER triangle (I >= J).
 //                  No LDS staging and no barriers: the k-major W panel is tiny
 //                  (k x N) and L2 resident, so each lane pulls its two operands
-//                  per MFMA straight from it; the wave needs 16 (f32) / 32
-//                  (f64) accumulator registers, so 8 / 4 waves per SIMD are
-//                  resident and the hardware overlaps one wave's P traffic with
-//                  other waves' matrix work.  An off-diagonal tile is computed
+//                  per MFMA straight from it.  f32: the operands go through a ring
+//                  of 3 register slots of 8 k-pairs (inline-asm loads, hand-counted
+//                  waits), < 96 registers per wave, so 5 waves per SIMD (4 above
+//                  k = 128) are resident and every tile of the n=1024 problem is in
+//                  flight from the start; the hardware overlaps one wave's P traffic
+//                  with other waves' matrix work.  An off-diagonal tile is computed
 //                  once and written twice: D to (I,J) and, transposed through a
 //                  wave-private LDS tile, D^T to (J,I).  Flops are halved
 //                  (N^2 k), P is read once per lower tile and written once.
 //                  f32: v_mfma_f32_32x32x2_f32, one accumulator.
-//                  f64: v_mfma_f64_16x16x4_f64, 2x2 accumulators.
+//                  f64: v_mfma_f64_16x16x4_f64, 2x2 accumulators (one workgroup per
+//                  tile / one sub-tile per wave for small problems).
 #include <hip/hip_ext.h>
 #include "ekf_kernels.h"
 
@@ -352,8 +355,9 @@ __global__ __launch_bounds__(256) void ekf_cov_rows_kernel(EkfFrame fr) {
     __shared__ T wr[192];                            // -W[:, row]
     const int slot = blockIdx.x;
     const int lmd = fr.model == 1 ? 10 : EKF_LM;     // state dims per landmark
-    const int row = (slot < EKF_CAM) ? slot
-                                     : EKF_CAM + lmd * fr.next_idx[(slot - EKF_CAM) / lmd] + (slot - EKF_CAM) % lmd;
+    int nidx = (slot < EKF_CAM) ? 0 : fr.next_idx[(slot - EKF_CAM) / lmd];
+    if ((unsigned)nidx >= (unsigned)fr.n_lm) nidx = 0;      // (reported by the next frame's kernels, which clamp the same way)
+    const int row = (slot < EKF_CAM) ? slot : EKF_CAM + lmd * nidx + (slot - EKF_CAM) % lmd;
     const T* __restrict__ wp = static_cast<const T*>(fr.wpanel);
     const T* __restrict__ P = static_cast<const T*>(fr.cov);
     T* __restrict__ out = static_cast<T*>(fr.prow_out);

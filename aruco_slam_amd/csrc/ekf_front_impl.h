@@ -18,9 +18,18 @@
 //                  carries a quaternion that straddles chunks).
 // Exchange between workgroups: ekf_solve_device.h (agent-scope relaxed accesses: write-through
 // stores, coherent loads, sentinel values; no flags, no global fences, no cache flushes).  The
-// factor buffers are double-buffered across frames and re-armed with sentinels by the S-block
-// workgroups of the following frame; the S exchange has a single consumer, which re-arms what it
-// has read.  Frame tags behind the Jacobian and behind every block column are an integrity check.
+// protocol needs exactly one hardware property, per-location coherence of agent-scope atomics:
+//   * every word a consumer uses is checked against the sentinel (the single polled word is only a
+//     hint for WHEN to fetch the bulk; a word that has not landed yet reads as the sentinel and is
+//     fetched again);
+//   * a buffer is armed with sentinels by ANOTHER launch: everything that travels inside a launch
+//     (S blocks, residual, -L / Dinv / y, Jacobian rows, tags) lives in one buffer per fused-frame
+//     parity, and the buffer of parity p is re-armed by the S-block workgroups of the following fused
+//     frame -- one kernel boundary after its last reader, one before its next writer.  No role
+//     re-arms what it has just read (round 1 did that for the S blocks);
+//   * producers publish the fused-frame number next to the data (per S block, residual, Jacobian,
+//     factor block column); a consumer that finds another frame's number next to data it has just
+//     accepted raises a status bit: stale words that are NOT sentinels cannot pass silently.
 // Rules learnt the hard way: a polled line is written by ONE full-line store;
 // one wave per workgroup polls; write-through stores stay off the pivot chain's waves; a wait for
 // a load also waits for every older store; LDS hand-overs need workgroup-scope fences, a volatile
@@ -90,7 +99,7 @@ __device__ __forceinline__ void fr_role_sblock(const EkfFrame& fr, int sb, int n
 #pragma unroll
     for (int a = 0; a < EKF_CAM; ++a) cam[a] = fr.state[a];
     if (fr.stamps && sb == 0 && tid == 0) fr.stamps[60] = wall_clock64();
-    if (tid < m) lmc[tid] = EKF_CAM + LMD * fr.idx[tid];
+    if (tid < m) lmc[tid] = ekf_lm_column(fr, LMD, tid, false);
     __syncthreads();
     // this thread's entry of U (slot, c2): its P values are requested before the measurement model
     // is evaluated, so the two dependent memory round trips overlap
@@ -159,10 +168,12 @@ __device__ __forceinline__ void fr_role_sblock(const EkfFrame& fr, int sb, int n
             v = acc;
         }
         ekf_stc(fr.xs + ((size_t)bj * fr.sblk_rows + r1) * 16 + c2, v);
+        if (tid == 0) ekf_stc(fr.xs_tag + 16 * bj + bi, fr.seqno);
     }
     if (fr.stamps && sb == nS - 1 && tid == 0) fr.stamps[61] = wall_clock64();
 
-    // re-arm the factor exchange buffer of the NEXT frame (the one frame t-1 used)
+    // re-arm the WHOLE exchange buffer of the next fused frame (the one the previous fused frame used:
+    // S blocks, residual, factor, Jacobian, tags); its readers finished at least one kernel boundary ago
     {
         const int64_t lo = (int64_t)fr.xl_len * sb / nS, hi = (int64_t)fr.xl_len * (sb + 1) / nS;
         const double sent = ekf_sent();
@@ -185,7 +196,7 @@ __device__ __forceinline__ void fr_role_measure(const EkfFrame& fr, double* sm) 
     double cam[EKF_CAM];
 #pragma unroll
     for (int a = 0; a < EKF_CAM; ++a) cam[a] = fr.state[a];
-    if (tid < fr.m) lmc[tid] = EKF_CAM + LMD * fr.idx[tid];
+    if (tid < fr.m) lmc[tid] = ekf_lm_column(fr, LMD, tid, true);      // (the role that reports a bad index)
     __syncthreads();
     fr_measure<MODEL>(fr, cam, lmc, hs, rsd, tid, true);
     __syncthreads();
@@ -194,7 +205,10 @@ __device__ __forceinline__ void fr_role_measure(const EkfFrame& fr, double* sm) 
     const int nel = fr.k * JC;
     for (int e = tid; e < nel; e += FR_T) ekf_stc(xj + e, hs[e]);
     for (int e = tid; e < fr.kpad; e += FR_T) ekf_stc(fr.xr + e, rsd[e]);
-    if (tid == 0) ekf_stc(fr.xl + fr.xl_tag, fr.seqno);
+    if (tid == 0) {
+        ekf_stc(fr.xl + fr.xl_tag, fr.seqno);
+        ekf_stc(fr.xl + fr.xl_tag + 16, fr.seqno);         // residual
+    }
     if (fr.stamps && tid == 0) fr.stamps[55] = wall_clock64();
 }
 
@@ -208,16 +222,23 @@ __device__ __forceinline__ void fr_role_measure(const EkfFrame& fr, double* sm) 
 // cacheable loads (sc1 stores are written through, see tools/xcd_exchange_probe.hip; nothing in this
 // launch has touched those lines before; whatever has not landed yet still reads as a sentinel and
 // is re-read coherently).
-struct FrBlockSrc { double* base; const double* w; bool resid; };
+// (the residual "block" is 16 words: lanes read it as words 2 (lane & 7), +1, twice -- the same two
+// 16-byte loads as for an S block, so the issue path has no divergent branch)
+struct FrBlockSrc { const double* p0; const double* p1; const double* w; const double* tag; };
 __device__ __forceinline__ FrBlockSrc fr_block_src(const EkfFrame& fr, int nb, int i, int tc, int lane) {
     FrBlockSrc s;
-    s.resid = i >= nb;
-    if (!s.resid) {
-        s.base = fr.xs + ((size_t)tc * fr.sblk_rows + EKF_RB * i) * 16;
-        s.w = s.base + 255;
+    if (i < nb) {
+        const double* base = fr.xs + ((size_t)tc * fr.sblk_rows + EKF_RB * i) * 16;
+        s.p0 = base + 2 * lane;
+        s.p1 = base + 128 + 2 * lane;
+        s.w = base + 255;
+        s.tag = fr.xs_tag + 16 * tc + i;
     } else {
-        s.base = fr.xr + EKF_RB * tc;
-        s.w = s.base + 15;
+        const double* base = fr.xr + EKF_RB * tc;
+        s.p0 = base + 2 * (lane & 7);
+        s.p1 = s.p0;
+        s.w = base + 15;
+        s.tag = fr.xl + fr.xl_tag + 16;
     }
     return s;
 }
@@ -225,48 +246,28 @@ __device__ __forceinline__ FrBlockSrc fr_block_src(const EkfFrame& fr, int nb, i
 // columns 2 (lane & 7), +1.  All exchange reads are coherent (sc1) loads; their cost is per instruction
 // (~400 cycles each when eight waves fetch at once), so the bulk uses 16-byte loads, written as inline asm
 // (the atomic builtins stop at 8 bytes): issue with fr_block_issue, then ONE fr_block_arrive for the
-// whole batch before the values are used.  Retries use the 8-byte builtin.
+// whole batch before the values are used.  Retries use the 8-byte builtin.  The block's frame tag travels
+// with the bulk (one more load in the same batch).
+// (tools/asm_load_hazards.py checks the generated code: nothing may touch the destination registers of
+// these loads between the issue and the wait -- the compiler does not know that they are in flight.)
 typedef double fr_d2 __attribute__((ext_vector_type(2)));
-struct FrBlockRaw { fr_d2 a, b; };
-__device__ __forceinline__ void fr_block_issue(FrBlockRaw& r, const FrBlockSrc& s, int lane) {
-    r.a = fr_d2{0.0, 0.0};
-    r.b = fr_d2{0.0, 0.0};
-    if (!s.resid) {
-        const double* p0 = s.base + 2 * lane;
-        const double* p1 = s.base + 128 + 2 * lane;
-        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r.a) : "v"(p0) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r.b) : "v"(p1) : "memory");
-    } else if (lane < EKF_RB) {
-        const double* p0 = s.base + lane;
-        double v;
-        asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v) : "v"(p0) : "memory");
-        r.a[0] = v;
-    }
+struct FrBlockRaw { fr_d2 a, b; double t; };
+__device__ __forceinline__ void fr_block_issue(FrBlockRaw& r, const FrBlockSrc& s) {
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r.a) : "v"(s.p0) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r.b) : "v"(s.p1) : "memory");
+    asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(r.t) : "v"(s.tag) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void fr_block_arrive(FrBlockRaw (&r)[N]) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int j = 0; j < N; ++j) asm volatile("" : "+v"(r[j].a), "+v"(r[j].b));       // uses stay below the wait
+    for (int j = 0; j < N; ++j) asm volatile("" : "+v"(r[j].a), "+v"(r[j].b), "+v"(r[j].t));       // uses stay below the wait
 }
 __device__ __forceinline__ sf64x4 fr_block_value(const FrBlockRaw& r) { return sf64x4{r.a[0], r.a[1], r.b[0], r.b[1]}; }
-__device__ __forceinline__ sf64x4 fr_block_load_coherent(const FrBlockSrc& s, int lane) {
-    sf64x4 v = {0.0, 0.0, 0.0, 0.0};
-    if (!s.resid) {
-        v[0] = ekf_ldc(s.base + 2 * lane);
-        v[1] = ekf_ldc(s.base + 2 * lane + 1);
-        v[2] = ekf_ldc(s.base + 128 + 2 * lane);
-        v[3] = ekf_ldc(s.base + 128 + 2 * lane + 1);
-    } else if (lane < EKF_RB) {
-        v[0] = ekf_ldc(s.base + lane);
-    }
-    return v;
-}
-__device__ __forceinline__ sf64x4 fr_block_load(const FrBlockSrc& s, int lane) {      // single block (ring mode)
-    FrBlockRaw r[1];
-    fr_block_issue(r[0], s, lane);
-    fr_block_arrive(r);
-    return fr_block_value(r[0]);
+// a tag that has not landed yet proves nothing; one that HAS landed must be this frame's
+__device__ __forceinline__ int fr_tag_stale(double tag, double seqno) { return !ekf_is_sent(tag) && tag != seqno; }
+__device__ __forceinline__ sf64x4 fr_block_load_coherent(const FrBlockSrc& s) {
+    return sf64x4{ekf_ldc(s.p0), ekf_ldc(s.p0 + 1), ekf_ldc(s.p1), ekf_ldc(s.p1 + 1)};
 }
 __device__ __forceinline__ bool fr_block_pending(const sf64x4& v) {
     const bool p = ekf_is_sent(v[0]) || ekf_is_sent(v[1]) || ekf_is_sent(v[2]) || ekf_is_sent(v[3]);
@@ -281,40 +282,31 @@ __device__ __forceinline__ void fr_block_wait(const FrBlockSrc& s, int& spin_fai
         ekf_poll_sleep();
     }
 }
-// the block's values are in `v` (cacheable attempt); anything still missing is re-read coherently
-__device__ __forceinline__ sf64x4 fr_block_settle(const FrBlockSrc& s, sf64x4 v, int lane, int& spin_fail) {
+// the block's values are in `v` (first attempt); every word that still reads as the sentinel is fetched again
+__device__ __forceinline__ sf64x4 fr_block_settle(const FrBlockSrc& s, sf64x4 v, int& spin_fail) {
     int it = 0;
     while (fr_block_pending(v)) {
         if (++it > EKF_SPIN_MAX) { spin_fail = 1; break; }
         ekf_poll_sleep();
-        v = fr_block_load_coherent(s, lane);
+        v = fr_block_load_coherent(s);
     }
     return v;
 }
-// Re-arm (single consumer).  Issued after ALL loads of a batch have been consumed (a wait for a load
-// also waits for every older store), written through (sc1) like the data and right away: with plain
-// stores, or with the re-arm postponed to the end of the role, n >= 3700 fails in 10-30 % of the runs.
-__device__ __forceinline__ void fr_block_rearm(const FrBlockSrc& s, int lane) {
-    const double sent = ekf_sent();
-    if (!s.resid) {
-#pragma unroll
-        for (int x = 0; x < 4; ++x) ekf_stc(s.base + x * 64 + lane, sent);     // whole cache lines per instruction
-    } else if (lane < EKF_RB) {
-        ekf_stc(s.base + lane, sent);
-    }
-}
-__device__ __forceinline__ sf64x4 fr_block_take(const FrBlockSrc& s, sf64x4 v, int lane, int& spin_fail) {
-    v = fr_block_settle(s, v, lane, spin_fail);
-    fr_block_rearm(s, lane);
-    return v;
+// single block (ring mode): bulk + tag, settled
+__device__ __forceinline__ sf64x4 fr_block_take(const FrBlockSrc& s, double seqno, int& spin_fail, int& stale) {
+    FrBlockRaw r[1];
+    fr_block_issue(r[0], s);
+    fr_block_arrive(r);
+    stale |= fr_tag_stale(r[0].t, seqno);
+    return fr_block_settle(s, fr_block_value(r[0]), spin_fail);
 }
 __device__ __forceinline__ void fr_block_put(const sf64x4& v, double* tgt, int kp, int nb, int i, int lane) {
+    const fr_d2 a = {v[0], v[1]}, b = {v[2], v[3]};
     if (i < nb) {
-        const fr_d2 a = {v[0], v[1]}, b = {v[2], v[3]};
         *reinterpret_cast<fr_d2*>(tgt + (EKF_RB * i + (lane >> 3)) * SV_CLD + 2 * (lane & 7)) = a;
         *reinterpret_cast<fr_d2*>(tgt + (EKF_RB * i + 8 + (lane >> 3)) * SV_CLD + 2 * (lane & 7)) = b;
-    } else if (lane < EKF_RB) {
-        tgt[kp * SV_CLD + lane] = v[0];
+    } else if (lane < 8) {
+        *reinterpret_cast<fr_d2*>(tgt + kp * SV_CLD + 2 * lane) = a;
     }
 }
 
@@ -329,7 +321,7 @@ __device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, int RS, doubl
     double* __restrict__ xlop = fr.xl;
     double* __restrict__ xdop = fr.xl + fr.xl_dop;
     double* __restrict__ xy = fr.xl + fr.xl_y;
-    int nstamp = 0, spin_fail = 0;
+    int nstamp = 0, spin_fail = 0, stale = 0;
 #define EKF_STAMP() do { if (fr.stamps && tid == 0) fr.stamps[nstamp] = clock64(); ++nstamp; } while (0)
     if (fr.stamps && tid == 0) fr.stamps[62] = wall_clock64();
     EKF_STAMP();
@@ -371,26 +363,26 @@ __device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, int RS, doubl
         FrBlockRaw raw[PB];
 #pragma unroll
         for (int j = 0; j < PB; ++j)
-            if (pi[j] >= 0) fr_block_issue(raw[j], ps[j], lane);
+            if (pi[j] >= 0) fr_block_issue(raw[j], ps[j]);
         fr_block_arrive(raw);
 #pragma unroll
-        for (int j = 0; j < PB; ++j) pv[j] = fr_block_value(raw[j]);
+        for (int j = 0; j < PB; ++j) {
+            pv[j] = fr_block_value(raw[j]);
+            if (pi[j] >= 0) stale |= fr_tag_stale(raw[j].t, fr.seqno);
+        }
     }
 #pragma unroll
     for (int j = 0; j < PB; ++j)
         if (pi[j] >= 0) {
-            pv[j] = fr_block_settle(ps[j], pv[j], lane, spin_fail);
+            pv[j] = fr_block_settle(ps[j], pv[j], spin_fail);
             fr_block_put(pv[j], colbuf(ptc[j]), kp, nb, pi[j], lane);
         }
-#pragma unroll
-    for (int j = 0; j < PB; ++j)
-        if (pi[j] >= 0) fr_block_rearm(ps[j], lane);
     for (int u0 = wave + NW * PB; u0 < ntot; u0 += NW) {
         int u = u0, tc = 0;
         while (u >= nb - tc + 1) { u -= nb - tc + 1; ++tc; }
         const FrBlockSrc s = fr_block_src(fr, nb, tc + u, tc, lane);
         fr_block_wait(s, spin_fail);
-        fr_block_put(fr_block_take(s, fr_block_load(s, lane), lane, spin_fail), colbuf(tc), kp, nb, tc + u, lane);
+        fr_block_put(fr_block_take(s, fr.seqno, spin_fail, stale), colbuf(tc), kp, nb, tc + u, lane);
     }
     __syncthreads();
     EKF_STAMP();
@@ -503,18 +495,18 @@ __device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, int RS, doubl
                         FrBlockRaw raw[PB];
 #pragma unroll
                         for (int j = 0; j < PB; ++j)
-                            if (i2[j] >= 0) fr_block_issue(raw[j], s2[j], lane);
+                            if (i2[j] >= 0) fr_block_issue(raw[j], s2[j]);
                         fr_block_arrive(raw);
 #pragma unroll
-                        for (int j = 0; j < PB; ++j) v2[j] = fr_block_value(raw[j]);
+                        for (int j = 0; j < PB; ++j) {
+                            v2[j] = fr_block_value(raw[j]);
+                            if (i2[j] >= 0) stale |= fr_tag_stale(raw[j].t, fr.seqno);
+                        }
                     }
 #pragma unroll
                     for (int j = 0; j < PB; ++j)
                         if (i2[j] >= 0)
-                            fr_block_put(fr_block_settle(s2[j], v2[j], lane, spin_fail), colbuf(t2[j]), kp, nb, i2[j], lane);
-#pragma unroll
-                    for (int j = 0; j < PB; ++j)
-                        if (i2[j] >= 0) fr_block_rearm(s2[j], lane);
+                            fr_block_put(fr_block_settle(s2[j], v2[j], spin_fail), colbuf(t2[j]), kp, nb, i2[j], lane);
                 }
             }
             if (pubonly && wave == NW - 1) {
@@ -533,15 +525,16 @@ __device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, int RS, doubl
                     if (!all_resident) {
                         const FrBlockSrc s = fr_block_src(fr, nb, i, tc, lane);
                         fr_block_wait(s, spin_fail);
-                        fr_block_put(fr_block_take(s, fr_block_load(s, lane), lane, spin_fail), colbuf(tc), kp, nb, i, lane);
+                        fr_block_put(fr_block_take(s, fr.seqno, spin_fail, stale), colbuf(tc), kp, nb, i, lane);
                     }
                     if (b >= 1) {
                         SvAcc a;
                         sv_acc_load(a, colbuf(tc), kp, i, c, g);
                         int q = 0;
                         for (; q < b && !(q + RS >= nb || b <= q + RS - 3); ++q) {}
-                        // coherent loads: a chunk on this XCD may have pulled a half-published copy of these lines into the L2
-                        sv_terms_glb<true>(a, xlop, xy, nb, i, tc, q, g, lane);
+                        // read-back of this workgroup's own publication (the column has left the LDS ring): coherent
+                        // loads, every word checked against the sentinel like any other exchange read
+                        spin_fail |= sv_terms_glb<true>(a, xlop, xy, nb, i, tc, q, g, lane);
                         for (; q < b; ++q) sv_term_lds(a, colbuf(q), kp, i, tc, c, g, (q & 1) != 0);
                         sv_acc_store(a, colbuf(tc), kp, i, c, g);
                     }
@@ -552,8 +545,8 @@ __device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, int RS, doubl
         EKF_STAMP();
     }
     if (wave == NW - 1) publish(nb - 1);
-    if ((bad | (spin_fail << 2)) && lane == 0) {
-        atomicOr(fr.status, bad | (spin_fail << 2));
+    if ((bad | spin_fail | stale) && lane == 0) {
+        atomicOr(fr.status, (bad ? EKF_ST_NOT_SPD : 0) | (spin_fail ? EKF_ST_TIMEOUT : 0) | (stale ? EKF_ST_STALE_S : 0));
         if (bad) {      // diagnostics: which waves saw it, and the first block column
             atomicOr(fr.status + 1, 1 << wave);
             atomicCAS(fr.status + 2, 0, badb);
@@ -649,7 +642,7 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
         }
         if (wv == 0 && lane == 0) {
             const double tag = ekf_ldc(fr.xl + fr.xl_tag + 1 + q);
-            if (!ekf_is_sent(tag) && tag != fr.seqno) atomicOr(fr.status, 32);
+            if (fr_tag_stale(tag, fr.seqno)) atomicOr(fr.status, EKF_ST_STALE_COL);
         }
         pf64x4 wq = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -741,7 +734,7 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
     T pcr[EKF_CAM];
 #pragma unroll
     for (int a = 0; a < EKF_CAM; ++a) pcr[a] = prow ? prow[(int64_t)a * fr.ldw + c] : P[a * ld + c];
-    if (tid < m) lmc[tid] = EKF_CAM + LMD * fr.idx[tid];
+    if (tid < m) lmc[tid] = ekf_lm_column(fr, LMD, tid, false);
     if (tid == 0) { flag[1] = 0; flag[2] = 0; }
     __syncthreads();
     T plr[NU][LMD];
@@ -777,10 +770,10 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
             }
             hs[e] = v;
         }
-        if (spin) atomicOr(fr.status, 4);
+        if (spin) atomicOr(fr.status, EKF_ST_TIMEOUT);
         if (tid == 0) {
             const double tag = ekf_ldc(fr.xl + fr.xl_tag);
-            if (!ekf_is_sent(tag) && tag != fr.seqno) atomicOr(fr.status, 16);
+            if (fr_tag_stale(tag, fr.seqno)) atomicOr(fr.status, EKF_ST_STALE_JAC);
         }
     }
     __syncthreads();
@@ -816,17 +809,20 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
     if (g < 4) {
         const int lane = tid & 63, col0 = chunk0 + 16 * g;
         fr_panel<T, NB, MODEL>(fr, a_lds, flag + 1, pshare, g, col0, lane, spin_fail);
-        if (spin_fail && (tid & 63) == 0) atomicOr(fr.status, 4);
+        if (spin_fail && (tid & 63) == 0) atomicOr(fr.status, EKF_ST_TIMEOUT);
     }
     if (MODEL == 0) return;
     // ---- EKF_Rotations: dx of this chunk has to be in memory before the chunk counts as done;
     // the last chunk injects (ekf_with_rotations.py:142-177): camera and every landmark: xyz
     // additive, quaternion multiplicative (scalar first); landmark error states are never written
+    // dx travels through memory between chunks on different XCDs: the counter increment is a RELEASE
+    // (this chunk's dx stores are performed at agent scope before it) and an ACQUIRE (the last chunk
+    // sees every other chunk's dx), i.e. the memory model's own guarantee, not a timing assumption
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
         const unsigned long long old =
-            __hip_atomic_fetch_add(fr.done_ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(fr.done_ctr, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         flag[0] = (old + 1 == fr.done_target);
     }
     __syncthreads();

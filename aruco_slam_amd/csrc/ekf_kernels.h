@@ -4,6 +4,14 @@
 #include <stdint.h>
 #include "ekf_device.h"
 
+// status word bits (sticky until ekf_reset; decoded by sync_and_check in ekf_api.hip)
+#define EKF_ST_NOT_SPD 1          // a pivot of the innovation covariance was not positive
+#define EKF_ST_TIMEOUT 4          // a bounded exchange wait inside the fused front kernel ran out
+#define EKF_ST_STALE_JAC 16       // a chunk accepted Jacobian rows that carry another frame's tag
+#define EKF_ST_STALE_COL 32       // a chunk accepted a factor block column that carries another frame's tag
+#define EKF_ST_STALE_S 64         // the factorisation accepted an S block / residual that carries another frame's tag
+#define EKF_ST_BAD_INDEX 128      // a landmark index outside [0, n_lm) reached a kernel (clamped to 0 there)
+
 // Everything one frame's kernels need; passed by value.
 struct EkfFrame {
     void* cov;             // P, f32 or f64, row-major, leading dim ld
@@ -38,7 +46,7 @@ struct EkfFrame {
     void* wpanel;          // W = L^-1 A, [kmax, ldw], cov dtype, k-major
     int64_t ldw;
     double* wdbg;          // optional f64 copy of W for tests (may be null)
-    int32_t* status;       // [0] != 0 -> non-SPD innovation covariance seen
+    int32_t* status;       // [0] sticky error bits (EKF_ST_*), [1..2] diagnostics of the first non-SPD block column
     double* traj_row;      // optional: state[0:7] after the update
     double* dxvec;         // model 1: dx = W^T y for every state dimension (input of the injection kernel)
     long long* stamps;     // optional: s_memtime stamps of the solve kernel's phases (diagnostics)
@@ -52,19 +60,39 @@ struct EkfFrame {
     const void* prow;          // read by the gather kernel; null = read P
     EkfNoise nz;
     int32_t quat_mode;
-    // fused front kernel (ekf_front_impl.h): exchange buffers between its workgroups
-    double* xs;                // S blocks, layout of sblk; sentinel-armed, re-armed by the consumer
-    double* xr;                // [kmax] z - h (0 for rows k..kpad-1)
-    double* xl;                // this frame's exchange: [-L operands | Dinv operands | y | Jacobian rows [k][JC]]
-    double* xl_next;           // the other buffer, re-armed during this frame for the next one
+    // fused front kernel (ekf_front_impl.h): exchange buffers between its workgroups.  ONE buffer per
+    // fused-frame parity holds everything that travels between workgroups inside a launch:
+    //   [-L operands | Dinv operands | y | Jacobian rows [k][JC] | tags | S blocks | residual | S-block tags]
+    // Every word is sentinel-armed (EKF_SENT_BITS) until its producer overwrites it; the buffer of
+    // parity p is re-armed during the NEXT fused frame (parity p^1) by that frame's S-block
+    // workgroups, i.e. at least one kernel boundary after its last reader and one before its next
+    // writer.  No role ever re-arms what it has just read.
+    double* xl;                // this frame's exchange buffer
+    double* xl_next;           // the other buffer, re-armed during this frame for the next fused frame
     int32_t xl_dop, xl_y, xl_jac;   // offsets (doubles) of the Dinv operands, y and the Jacobian rows inside xl
     int32_t xl_len;            // doubles per buffer
-    int32_t n_lm;              // landmarks in the state (model 1 injection)
+    double* xs;                // = xl + offset: S blocks, layout of sblk
+    double* xr;                // = xl + offset: [kmax] z - h (0 for rows k..kpad-1)
+    double* xs_tag;            // = xl + offset: frame tag of S block (row block i, block column tc) at [16 tc + i]
+    int32_t n_lm;              // landmarks in the state (index validation; model 1 injection)
     unsigned long long* done_ctr;      // chunks finished since reset (device)
     unsigned long long done_target;    // value of done_ctr once this frame's last chunk is done
-    int32_t xl_tag;                    // frame tags inside xl ([0] Jacobian, [1 + q] block column q): integrity check
-    double seqno;                      // this frame's tag
+    int32_t xl_tag;                    // frame tags inside xl ([0] Jacobian, [1 + q] block column q, [16] residual): integrity check
+    double seqno;                      // this frame's tag (fused frames since reset, from 1)
 };
+
+// First state column of detection j.  Indices that arrive through the device-pointer entry points
+// cannot be checked on the host: an index outside [0, n_lm) is clamped to 0 (so that nothing is read
+// or written out of bounds) and, where `flag` is set, recorded in the status word -> EKF_ERR_INVALID
+// at the next synchronising call.
+__device__ __forceinline__ int ekf_lm_column(const EkfFrame& fr, int lmd, int j, bool flag) {
+    int i = fr.idx[j];
+    if ((unsigned)i >= (unsigned)fr.n_lm) {
+        if (flag) atomicOr(fr.status, EKF_ST_BAD_INDEX);
+        i = 0;
+    }
+    return EKF_CAM + lmd * i;
+}
 
 // fused gather + solve + panel (+ injection); see ekf_front_impl.h
 template <typename T> void ekf_launch_front(const EkfFrame& fr, hipStream_t s);

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void ekf_gather_kernel(EkfFrame fr) {
     double cam[EKF_CAM];
 #pragma unroll
     for (int a = 0; a < EKF_CAM; ++a) cam[a] = fr.state[a];
-    if (tid < m) lmc[tid] = EKF_CAM + LMD * fr.idx[tid];
+    if (tid < m) lmc[tid] = ekf_lm_column(fr, LMD, tid, blockIdx.x == 0);
     __syncthreads();
     // landmark rows of P for this wave's detections (A chunks)
     T plr[NU][LMD];

@@ -91,27 +91,44 @@ __device__ __forceinline__ void sv_term_lds(SvAcc& a, const double* qbuf, int kp
         for (int r = 0; r < 4; ++r) a.t = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[r], bv[r], a.t, 0, 0, 0);
     }
 }
-// q in [0, q1), operands from global: lop (-L blocks) and, for the residual block, y
+// q in [0, q1), operands from global: lop (-L blocks) and, for the residual block, y.
+// COH (fused front kernel, ring mode): the operands are this workgroup's own publication in the
+// exchange buffer, read back with coherent loads; every word is checked against the sentinel and
+// fetched again until it has landed (returns 1 if a bounded wait ran out).
 template <bool COH = false>
-__device__ __forceinline__ void sv_terms_glb(SvAcc& a, const double* __restrict__ lop,
-                                             const double* __restrict__ yv, int nb, int i, int tc, int q1,
-                                             int g, int lane) {
-    if (q1 <= 0) return;
+__device__ __forceinline__ int sv_terms_glb(SvAcc& a, const double* __restrict__ lop,
+                                            const double* __restrict__ yv, int nb, int i, int tc, int q1,
+                                            int g, int lane) {
+    if (q1 <= 0) return 0;
+    int fail = 0;
     // operands of term q+1 are in flight while the MFMAs of term q run
     double av[4], bv[4], an[4], bn[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        av[r] = (i < nb) ? ekf_ldx<COH>(lop + sv_lop_index(i, 0) + r * 64 + lane) : -ekf_ldx<COH>(yv + g + 4 * r);
-        bv[r] = -ekf_ldx<COH>(lop + sv_lop_index(tc, 0) + r * 64 + lane);
-    }
-    for (int q = 0; q < q1; ++q) {
-        const int qn = min(q + 1, q1 - 1);
+    auto fetch = [&](int q, double (&x)[4], double (&y)[4]) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            an[r] = (i < nb) ? ekf_ldx<COH>(lop + sv_lop_index(i, qn) + r * 64 + lane)
-                             : -ekf_ldx<COH>(yv + EKF_RB * qn + g + 4 * r);
-            bn[r] = -ekf_ldx<COH>(lop + sv_lop_index(tc, qn) + r * 64 + lane);
+            x[r] = (i < nb) ? ekf_ldx<COH>(lop + sv_lop_index(i, q) + r * 64 + lane)
+                            : -ekf_ldx<COH>(yv + EKF_RB * q + g + 4 * r);
+            y[r] = -ekf_ldx<COH>(lop + sv_lop_index(tc, q) + r * 64 + lane);
         }
+    };
+    auto settle = [&](int q, double (&x)[4], double (&y)[4]) {
+        if (!COH) return;
+        int it = 0;
+        for (;;) {
+            bool pend = false;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pend = pend || ekf_is_sent(x[r]) || ekf_is_sent(-x[r]) || ekf_is_sent(y[r]) || ekf_is_sent(-y[r]);
+            if (!__any(pend)) break;
+            if (++it > EKF_SPIN_MAX) { fail = 1; break; }
+            __builtin_amdgcn_s_sleep(4);
+            fetch(q, x, y);
+        }
+    };
+    fetch(0, av, bv);
+    for (int q = 0; q < q1; ++q) {
+        const int qn = min(q + 1, q1 - 1);
+        fetch(qn, an, bn);
+        settle(q, av, bv);
         if (q & 1) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) a.t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[r], bv[r], a.t2, 0, 0, 0);
@@ -122,6 +139,7 @@ __device__ __forceinline__ void sv_terms_glb(SvAcc& a, const double* __restrict_
 #pragma unroll
         for (int r = 0; r < 4; ++r) { av[r] = an[r]; bv[r] = bn[r]; }
     }
+    return fail;
 }
 
 // S entries of row block i of block column tc (rows 16i.., columns 16tc..): one wave, lane =

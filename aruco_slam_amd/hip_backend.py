@@ -25,7 +25,8 @@ EXPORTED_SYMBOLS = (
     "ekf_reset", "ekf_add_markers", "ekf_observe", "ekf_observe_device",
     "ekf_observe_sequence_device", "ekf_get_camera", "ekf_get_state", "ekf_get_cov_diag",
     "ekf_get_cov", "ekf_set_state", "ekf_set_cov", "ekf_num_landmarks", "ekf_sync",
-    "ekf_set_kernel_timing", "ekf_get_kernel_timing", "ekf_debug_fetch", "ekf_last_error_string",
+    "ekf_set_fused", "ekf_set_kernel_timing", "ekf_get_kernel_timing", "ekf_debug_fetch",
+    "ekf_last_error_string",
 )
 
 
@@ -84,6 +85,7 @@ def load_library(path: str | Path | None = None):
         "ekf_set_cov": [vp, dp, C.c_int32],
         "ekf_num_landmarks": [vp],
         "ekf_sync": [vp],
+        "ekf_set_fused": [vp, C.c_int32],
         "ekf_set_kernel_timing": [vp, C.c_int32],
         "ekf_get_kernel_timing": [vp, C.c_int32, dp, C.POINTER(C.c_int64)],
         "ekf_debug_fetch": [vp, C.c_int32, dp, C.c_size_t],
@@ -127,11 +129,9 @@ class HipEkf:
         kern = {"auto": EKF_COVK_AUTO, "valu": EKF_COVK_VALU, "mfma": EKF_COVK_MFMA}
         cfg.cov_kernel = kern[cov_kernel]
         cfg.flags = {None: 0, False: 1, True: 2}[lookahead]   # None / False: serial order (default)
-        if fused == "force":
-            cfg.flags |= 8        # fused front kernel even where it is not trusted yet (diagnostics)
-        elif not fused:
+        if not fused:
             cfg.flags |= 4        # separate gather / solve / panel launches
-        self.fused = fused if fused == "force" else bool(fused)
+        self.fused = bool(fused)  # ("force" of earlier versions == True: there is no automatic fallback any more)
         self._last_m = 1
         cfg.model = {"ekf": 0, "ekf_rotations": 1}[model]
         self.lm_dims, self.rows_per_detection = (10, 7) if cfg.model == 1 else (3, 3)
@@ -255,21 +255,15 @@ class HipEkf:
             us, cnt = C.c_double(), C.c_int64()
             self._check(self.lib.ekf_get_kernel_timing(self.h, i, C.byref(us), C.byref(cnt)))
             out[name] = (us.value, cnt.value)
-        if self.front_kernel_used(self._last_m):
+        if self.fused:
             # one launch: slot 0 is the whole front kernel, slots 1-2 are empty event gaps
             out = {"front": out["gather"], "cov_update": out["cov_update"]}
         return out
 
-    def front_kernel_used(self, m: int) -> bool:
-        """Mirror of use_front_kernel() in csrc/ekf_api.hip: fused front kernel or the three stage kernels?"""
-        if self.fused == "force":
-            return True
-        if not self.fused:
-            return False
-        kpad = -(-self.rows_per_detection * max(int(m), 1) // 16) * 16
-        nb = kpad // 16
-        grid = nb * (nb + 1) // 2 + 2 + (-(-self.dims // 128) * 128) // 64
-        return kpad <= 128 or grid <= 200
+    def set_fused(self, enable: bool):
+        """Fused front kernel (True) or the three stage kernels (False) from the next frame on."""
+        self._check(self.lib.ekf_set_fused(self.h, int(bool(enable))))
+        self.fused = bool(enable)
 
     def debug_enable_w(self):
         dummy = np.zeros(1)

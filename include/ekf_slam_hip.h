@@ -53,7 +53,8 @@ enum {
     EKF_ERR_CAPACITY = -2,  /* more landmarks / observations than configured */
     EKF_ERR_HIP = -3,       /* a HIP runtime call failed */
     EKF_ERR_STATE = -4,     /* buffers not bound, filter not reset, ... */
-    EKF_ERR_NUMERIC = -5    /* innovation covariance not positive definite */
+    EKF_ERR_NUMERIC = -5    /* innovation covariance not positive definite, or an internal integrity check of the
+                             * front kernel's in-launch exchange tripped */
 };
 
 typedef struct ekf_config {
@@ -67,8 +68,7 @@ typedef struct ekf_config {
     int32_t flags;          /* bit 1: cross-frame lookahead in ekf_observe_sequence_device (priority rows +
                              * covariance update on a second stream; same results, currently slower than
                              * the serial order at every size, off by default; bit 0 is ignored).  bit 2: run gather / solve / panel as three separate
-                             * launches instead of the fused front kernel (same results, bit for bit; also chosen
-                             * automatically for k > 128 with more than 200 workgroups).  bit 3: always fused. */
+                             * launches instead of the fused front kernel (same results, bit for bit).  bit 3 is ignored. */
     /* noise constants, defaults = extended_kalman_filter.py:21-27 */
     double initial_camera_uncertainty;   /* 0.1  */
     double initial_landmark_uncertainty; /* 0.7  */
@@ -114,9 +114,12 @@ int ekf_add_markers(ekf_filter *f, const double *cam_frame_xyz,
  * lm_index [m] = landmark indices of the visible markers in `ids` order
  * (duplicates legal), z [m,3] = pose[0:3] of every detection (EKF_MODEL_ROTATIONS: z [m,7] =
  * [pose[0:3] | quaternion of from_euler("xyz", pose[3:6]), scalar first], :216-224).
- * ekf_observe takes host pointers (copied during the call);
+ * ekf_observe takes host pointers (copied during the call; indices are range-checked at once);
  * ekf_observe_device takes device pointers that must stay valid until the
- * stream has consumed them. */
+ * stream has consumed them.  Device-resident indices are range-checked BY THE KERNELS: an index
+ * outside [0, num_landmarks) is clamped (nothing is read or written out of bounds) and reported as
+ * EKF_ERR_INVALID by the next synchronising call (ekf_sync, any getter); the error is sticky until
+ * ekf_reset, because the frames computed from clamped indices have already changed the filter. */
 int ekf_observe(ekf_filter *f, const int32_t *lm_index, const double *z, int32_t m);
 int ekf_observe_device(ekf_filter *f, const int32_t *lm_index_dev,
                        const double *z_dev, int32_t m);
@@ -149,6 +152,11 @@ int ekf_set_cov(ekf_filter *f, const double *cov, int32_t dims);
 
 int ekf_num_landmarks(const ekf_filter *f);
 int ekf_sync(ekf_filter *f);
+
+/* Front part of the update (measurement model, S, Cholesky, W, dx, injection): enable != 0 = the
+ * fused front kernel (default), 0 = the three stage kernels (gather / solve / panel).  Same results,
+ * bit for bit; may be switched between any two frames (same as ekf_config.flags bit 2). */
+int ekf_set_fused(ekf_filter *f, int32_t enable);
 
 /* Per-kernel device timing with HIP events on the handle's stream.
  * which: 0 gather, 1 solve, 2 panel, 3 covariance update.

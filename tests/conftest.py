@@ -31,6 +31,33 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
 
 
+def rel_err_elem(a, b, floor=1e-3):
+    """Element-wise relative error max_i |a_i - b_i| / max(|b_i|, floor).  Most trajectory / map /
+    covariance entries are < 1, so ``rel_err`` (normalised by max(1, max|b|)) is an ABSOLUTE error
+    on them; this one is relative for every entry larger than ``floor`` and absolute (in units of
+    ``floor``) below it."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float((np.abs(a - b) / np.maximum(np.abs(b), floor)).max())
+
+
+def report(test, **values):
+    """Measured parity numbers of the GPU tests, one JSON line each, into
+    ``gpurun_out/parity_metrics.jsonl`` (scratch; the summary that is judged is copied to
+    ``profiles/``) and onto stdout (``pytest -s``)."""
+    import json
+    line = json.dumps({"test": test, **{k: (float(v) if isinstance(v, (int, float, np.floating)) else v)
+                                        for k, v in values.items()}})
+    print("PARITY", line)
+    out = REPO / "gpurun_out"
+    try:
+        out.mkdir(exist_ok=True)
+        with (out / "parity_metrics.jsonl").open("a") as fh:
+            fh.write(line + "\n")
+    except OSError:
+        pass
+
+
 def chaos_horizon(free_run, envelope=1e-8):
     """Last frame up to which the reference reproduces ITSELF: the fixture
     holds a second reference run on inputs perturbed by 1e-15 (relative); the

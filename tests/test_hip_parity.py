@@ -11,12 +11,18 @@ Tolerances (relative = max|a-b| / max(1, max|b|)):
 import numpy as np
 import pytest
 
-from conftest import chaos_horizon, load_npz, rel_err
+from conftest import chaos_horizon, load_npz, rel_err, rel_err_elem, report
 
 pytestmark = pytest.mark.gpu
 
 INIT = np.array([0, 0, 0, 1, 0, 0, 0, 0, 0, 0])
 STEP_TOL = {"float64": 1e-10, "float32": 2e-5}
+# element-wise relative bound per teacher-forced step, |a-b| <= tol * max(|b|, 1e-3) for EVERY entry
+# (conftest.rel_err_elem; the norm-wise STEP_TOL above is an absolute bound on entries < 1).  Set from
+# the measured values (profiles/r02_parity_metrics.json): fp64 ~1e-11, fp32 covariance ~5e-4 on the
+# smallest covariance entries (1e-3 .. 1e-2 in magnitude, stored with 24-bit mantissas after a
+# rank-k downdate that cancels most of their magnitude).
+ELEM_TOL = {"float64": 1e-9, "float32": 5e-3}
 
 
 def _ekf(**kw):
@@ -89,13 +95,18 @@ def test_intermediates_one_step(dtype):
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_g2_teacher_forced_vs_reference(dtype):
     g = load_npz("g2_teacher_forced.npz")
+    worst = np.zeros(4)
     for f in g["frames"]:
         flt = _ekf(max_landmarks=16, max_visible=8, cov_dtype=dtype)
         _restore_hip(flt, g[f"f{f}_state0"], g[f"f{f}_P0"], g[f"f{f}_lm_ids"])
         flt.observe(list(g[f"f{f}_ids"]), g[f"f{f}_poses"])
         assert flt.state.shape == g[f"f{f}_state1"].shape
-        assert rel_err(flt.state, g[f"f{f}_state1"]) <= STEP_TOL[dtype], f
-        assert rel_err(flt.uncertainty, g[f"f{f}_P1"]) <= STEP_TOL[dtype], f
+        p1 = flt.uncertainty
+        worst = np.maximum(worst, [rel_err(flt.state, g[f"f{f}_state1"]), rel_err(p1, g[f"f{f}_P1"]),
+                                   rel_err_elem(flt.state, g[f"f{f}_state1"]), rel_err_elem(p1, g[f"f{f}_P1"])])
+    report(f"g2_teacher_forced[{dtype}]", state_norm=worst[0], cov_norm=worst[1], state_elem=worst[2], cov_elem=worst[3])
+    assert worst[0] <= STEP_TOL[dtype] and worst[1] <= STEP_TOL[dtype], worst
+    assert worst[2] <= ELEM_TOL[dtype] and worst[3] <= ELEM_TOL[dtype], worst
 
 
 @pytest.mark.parametrize("dtype,kernel", [("float64", "mfma"), ("float64", "valu"),
@@ -194,15 +205,24 @@ def test_g4_scale_vs_reference(name, dtype, tol):
         flt.observe(g["ids"][f], poses)
     assert rel_err(flt.state, g["boot_state"]) <= tol
     assert rel_err(flt.backend.get_cov_diag(), g["boot_diag"]) <= tol
+    worst = np.zeros(6)
     for j in range(g["states"].shape[0]):
         poses[:, :3] = g["z"][boot + j]
         flt.observe(g["ids"][boot + j], poses)
-        assert rel_err(flt.state, g["states"][j]) <= tol
-        assert rel_err(flt.backend.get_cov_diag(), g["diags"][j]) <= tol
+        st, dg = flt.state, flt.backend.get_cov_diag()
+        worst[:4] = np.maximum(worst[:4], [rel_err(st, g["states"][j]), rel_err(dg, g["diags"][j]),
+                                           rel_err_elem(st, g["states"][j]), rel_err_elem(dg, g["diags"][j])])
     p = flt.uncertainty
     assert abs(np.linalg.norm(p) - g["fro"][-1]) <= tol * g["fro"][-1]
     for (r, c), blk in zip(g["block_corners"], g["blocks"][-1]):
-        assert rel_err(p[r:r + 16, c:c + 16], blk) <= tol
+        worst[4:] = np.maximum(worst[4:], [rel_err(p[r:r + 16, c:c + 16], blk), rel_err_elem(p[r:r + 16, c:c + 16], blk)])
+    report(f"g4_scale[{name},{dtype}]", state_norm=worst[0], diag_norm=worst[1], state_elem=worst[2], diag_elem=worst[3],
+           blocks_norm=worst[4], blocks_elem=worst[5])
+    assert worst[0] <= tol and worst[1] <= tol and worst[4] <= tol, worst
+    # element-wise: state and variances (all well above the 1e-3 floor) to the same bound; sampled
+    # off-diagonal blocks hold entries down to 1e-6, i.e. mostly the absolute floor
+    etol = {"float64": 1e-7, "float32": 5e-3}[dtype]
+    assert worst[2] <= etol and worst[3] <= etol and worst[5] <= etol, worst
     assert np.array_equal(p, p.T)          # bitwise symmetric
 
 
@@ -407,14 +427,20 @@ def _rot(**kw):
 def test_g5_rotations_teacher_forced_vs_reference(dtype):
     g = load_npz("g5_rotations.npz")
     offs = g["offsets"]
+    worst = np.zeros(4)
     for f in g["frames"]:
         flt = _rot(max_landmarks=8, max_visible=6, cov_dtype=dtype)
         _restore_hip(flt, g[f"f{f}_state0"], g[f"f{f}_P0"], g[f"f{f}_lm_ids"])
         sl = slice(offs[f], offs[f + 1])
         flt.observe(list(g["ids"][sl]), g["poses"][sl])
         assert flt.state.shape == g[f"f{f}_state1"].shape
-        assert rel_err(flt.state, g[f"f{f}_state1"]) <= STEP_TOL[dtype], f
-        assert rel_err(flt.uncertainty, g[f"f{f}_P1"]) <= STEP_TOL[dtype], f
+        p1 = flt.uncertainty
+        worst = np.maximum(worst, [rel_err(flt.state, g[f"f{f}_state1"]), rel_err(p1, g[f"f{f}_P1"]),
+                                   rel_err_elem(flt.state, g[f"f{f}_state1"]), rel_err_elem(p1, g[f"f{f}_P1"])])
+    report(f"g5_rotations_teacher_forced[{dtype}]", state_norm=worst[0], cov_norm=worst[1], state_elem=worst[2],
+           cov_elem=worst[3])
+    assert worst[0] <= STEP_TOL[dtype] and worst[1] <= STEP_TOL[dtype], worst
+    assert worst[2] <= ELEM_TOL[dtype] and worst[3] <= ELEM_TOL[dtype], worst
 
 
 def test_g5_rotations_intermediates():
@@ -601,8 +627,10 @@ def test_large_k_runs_are_repeatable_bitwise():
 
 def test_c5_size_back_to_back_frames_fused_vs_separate_launches():
     """n=4096, m=64 (C5): the front kernel has more workgroups than the GPU has CUs (late-starting
-    chunks) and every bounded wait is long; 40 frames back to back through the sequence entry point,
-    one filter at a time, must give the bits of the separate launches."""
+    chunks), the factorisation streams its block columns through the LDS ring and reads its own
+    publication back, every bounded wait is long; 40 frames back to back through the sequence entry
+    point, one filter at a time, must give the bits of the separate launches.  ``fused=True`` IS the
+    fused kernel at this size (round 1 silently fell back to the stage kernels here)."""
     import torch
     from aruco_slam_amd.synthetic import SyntheticStream
     n, m = 4096, 64
@@ -614,6 +642,7 @@ def test_c5_size_back_to_back_frames_fused_vs_separate_launches():
     outs = []
     for fused in (True, False, True):
         flt = _ekf(max_landmarks=n, max_visible=m, cov_dtype="float32", fused=fused)
+        assert flt.backend.fused is fused
         for ids, poses in boot:
             flt.observe(ids, poses)
         flt.backend.observe_sequence(idx, z, None)
@@ -623,3 +652,158 @@ def test_c5_size_back_to_back_frames_fused_vs_separate_launches():
     for other in outs[1:]:
         assert np.array_equal(outs[0][0], other[0])
         assert np.array_equal(outs[0][1], other[1])
+
+
+def test_c5_full_size_properties_and_oracle_steps():
+    """BASELINE configs[4] (n=4096, m=64, N=12298, k=192, f32 covariance) through the fused front kernel:
+    (i) properties of one update at full size -- downdate identity P' + W^T W = P + Q with the debug copy
+    of W, bitwise symmetry, zero capacity padding, variances positive and not growing beyond P + Q;
+    (ii) three steady frames against the CPU oracle (fast mode) started from the SAME (state, P): the
+    bootstrap (128 frames of 32 new markers... here 64 frames of 64) runs on the GPU only -- the oracle's
+    add_marker reallocates N x N per marker -- and its result is handed to the oracle, so the comparison
+    covers the steady-state frames, the thing C5 is about (reference: extended_kalman_filter.py:95-156,
+    2 N^3 = 3.7 TF per frame there)."""
+    from aruco_slam_amd.synthetic import SyntheticStream
+    n, m = 4096, 64
+    dims = 3 * n + 10
+    s = SyntheticStream(n, m, seed=5)
+    flt = _ekf(max_landmarks=n, max_visible=m, cov_dtype="float32", quat_update="scalar_first")
+    assert flt.backend.fused is True
+    flt.backend.debug_enable_w()
+    for ids, poses in s.bootstrap():
+        flt.observe(ids, poses)
+    steady = [(ids.copy(), poses.copy()) for ids, poses in s.steady(6)]
+    for ids, poses in steady[:2]:
+        flt.observe(ids, poses)
+    state0, p0 = flt.state, flt.uncertainty
+    # ---- (ii) oracle from the same prior
+    orc = _oracle(mode="fast", quat_mode="scalar_first")
+    _restore_oracle(orc, state0, p0, list(range(n)))
+    q = np.full(dims, 0.01)
+    q[0:3], q[3:7], q[7:10] = 0.3, 0.0, 0.5
+    worst = np.zeros(4)
+    for t, (ids, poses) in enumerate(steady[2:5]):
+        flt.observe(ids, poses)
+        orc.observe(list(ids), poses)
+        st, dg = flt.state, flt.backend.get_cov_diag()
+        od = np.diagonal(orc.uncertainty)
+        worst = np.maximum(worst, [rel_err(st, orc.state), rel_err(dg, od), rel_err_elem(st, orc.state),
+                                   rel_err_elem(dg, od)])
+        if t == 0:
+            # ---- (i) properties of this update
+            p1 = flt.uncertainty
+            w = flt.backend.debug_fetch("W", m)[:3 * m]
+            lhs = p1 + w.T @ w
+            ident = rel_err(lhs, p0 + np.diag(q))
+            del lhs
+            assert ident <= 5e-6, ident
+            assert np.array_equal(p1, p1.T)
+            d1 = np.diagonal(p1)
+            assert (d1 > 0).all() and (d1 <= np.diagonal(p0) + q + 1e-6).all()
+            cov_t = flt.backend.cov_t
+            assert float(cov_t[dims:, :].abs().max()) == 0.0 and float(cov_t[:, dims:].abs().max()) == 0.0
+            full = rel_err(p1, orc.uncertainty)
+            assert full <= 2e-5, full
+            del p1
+    report("c5_oracle_steps[float32]", state_norm=worst[0], diag_norm=worst[1], state_elem=worst[2], diag_elem=worst[3],
+           downdate_identity=ident, cov_norm_step1=full)
+    assert worst[0] <= 1e-4 and worst[1] <= 1e-4, worst
+    assert worst[2] <= 5e-3 and worst[3] <= 5e-3, worst
+
+
+@pytest.mark.parametrize("make,n,m,dtype", [(_ekf, 300, 20, "float32"), (_ekf, 128, 64, "float64"), (_rot, 40, 12, "float32")])
+def test_stage_and_fused_frames_alternate_inside_one_filter(make, n, m, dtype):
+    """A filter may switch between the fused front kernel and the stage kernels between any two frames
+    (ekf_set_fused).  The exchange bookkeeping (buffer parity, frame tags, chunk counter of the
+    EKF_Rotations injection) advances with the FUSED frames only; round 1 advanced it with every frame, so
+    an odd number of stage frames left the next fused frame on a buffer that still held an older
+    frame's factor.  Alternating run == all-stage run, bit for bit, and no stale-exchange status."""
+    from aruco_slam_amd.synthetic import SyntheticStream
+    pattern = [True, False, True, True, False, False, False, True, False, True, True, True, False, True]
+    outs = []
+    for alternate in (True, False):
+        s = SyntheticStream(n, m, seed=7, rvec_sigma=0.05)
+        flt = make(max_landmarks=n, max_visible=m, cov_dtype=dtype, fused=False)
+        for ids, poses in s.bootstrap():
+            flt.observe(ids, poses)
+        for fused, (ids, poses) in zip(pattern, s.steady(len(pattern))):
+            flt.backend.set_fused(fused and alternate)
+            mm = m if fused else max(1, m // 2)              # the visible count changes as well
+            flt.observe(ids[:mm], poses[:mm])
+        flt.backend.sync()
+        outs.append((flt.state, flt.uncertainty))
+    assert np.isfinite(outs[0][0]).all()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_device_resident_bad_index_is_clamped_and_reported():
+    """ekf_observe_device / ekf_observe_sequence_device cannot range-check resident indices on the host:
+    the kernels clamp them (no out-of-bounds access) and the next synchronising call returns
+    EKF_ERR_INVALID, for the fused and for the stage kernels; a clean filter is unaffected."""
+    import torch
+    from aruco_slam_amd.hip_backend import EkfError
+    from aruco_slam_amd.synthetic import SyntheticStream
+    n, m = 64, 8
+    for fused in (True, False):
+        s = SyntheticStream(n, m, seed=2)
+        flt = _ekf(max_landmarks=n, max_visible=m, cov_dtype="float32", fused=fused)
+        for ids, poses in s.bootstrap():
+            flt.observe(ids, poses)
+        frames = list(s.steady(3))
+        idx = torch.tensor(np.stack([f[0] for f in frames]), dtype=torch.int32, device="cuda")
+        z = torch.tensor(np.stack([f[1][:, :3] for f in frames]), dtype=torch.float64, device="cuda")
+        flt.backend.observe_sequence(idx[:1], z[:1], None)
+        flt.backend.sync()                                   # clean so far
+        idx[1, 3] = n + 1000                                 # far outside the state
+        idx[2, 0] = -5
+        flt.backend.observe_sequence(idx[1:], z[1:], None)
+        with pytest.raises(EkfError) as e:
+            flt.backend.sync()
+        assert e.value.code == -1 and "index" in str(e.value)
+        with pytest.raises(EkfError):                        # sticky until reset
+            flt.backend.get_state()
+
+
+def test_map_file_restore_on_the_hip_filter_vs_oracle(golden_dir):
+    """f4: ``EKF(init, map_file=...)`` -> BaseFilter.load_map -> add_marker(id, pose, uncertainty) on the
+    real filter (base_filter.py:249-272 as intended, extended_kalman_filter.py:279-285), against the oracle
+    fed the same add_marker sequence; then a few observe steps on the restored map, one of them with
+    a marker the map does not hold."""
+    from aruco_slam_amd.filters.base_filter import BaseFilter
+    path = str(golden_dir / "g3_map.txt")
+    flt = _ekf(max_landmarks=16, max_visible=8, map_file=path)
+
+    class _Feed(BaseFilter):                                  # load_map's parser -> oracle.add_marker
+        def __init__(self, orc):
+            self.orc = orc
+
+        def add_marker(self, idx, pose, uncertainty=None):
+            self.orc.add_marker(idx, pose, uncertainty)
+
+    orc = _oracle(mode="fast")
+    _Feed(orc).load_map(path)
+    g = load_npz("g3_free_run.npz")
+    assert list(flt.landmarks.items()) == list(orc.landmarks.items())
+    assert [k for k, _ in flt.landmarks.items()] == list(g["lm_ids"])
+    assert np.array_equal(flt.state, np.asarray(orc.state, dtype=np.float64))
+    assert np.array_equal(flt.uncertainty, orc.uncertainty)
+    det = load_npz("c1_detections.npz")
+    offs = det["offsets"]
+    steps = 0
+    for f in range(len(det["timestamps_ms"])):
+        if not det["has_detections"][f]:
+            continue
+        sl = slice(offs[f], offs[f + 1])
+        ids, poses = list(det["ids"][sl]), det["poses"][sl].copy()
+        if steps == 2:
+            ids = ids + [49]                                  # a marker the map does not know
+            poses = np.vstack([poses, [[0.3, -0.2, 4.0, 0, 0, 0]]])
+        flt.observe(ids, poses)
+        orc.observe(ids, poses)
+        assert rel_err(flt.state, orc.state) <= 1e-10
+        assert rel_err(flt.uncertainty, orc.uncertainty) <= 1e-10
+        steps += 1
+        if steps == 5:
+            break
+    assert flt.num_landmarks == orc.num_landmarks == len(g["lm_ids"]) + 1

@@ -228,3 +228,31 @@ def test_hand_counted_kernels_do_not_spill(tmp_path):
     assert all(int(spills) == 0 for _, spills in kernels), kernels
     scratch = re.findall(r"\.name:\s+(\S*ekf_cov_update_mfma_f32\S*)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", text)
     assert all(int(b) == 0 for _, b in scratch), scratch
+
+
+def test_hand_issued_loads_are_not_touched_before_their_wait(tmp_path):
+    """The front kernel (16-byte coherent exchange loads) and the f32 covariance update (operand ring)
+    issue loads from inline asm; the compiler does not know that their destination registers are in
+    flight.  tools/asm_load_hazards.py walks the generated code: no instruction may touch such a register
+    between the load and the s_waitcnt that covers it (a copy or spill there would read stale register
+    contents whenever memory is slow -- a timing-dependent wrong result)."""
+    import subprocess
+    import sys
+    from concurrent.futures import ThreadPoolExecutor
+    from aruco_slam_amd import _build
+    sys.path.insert(0, str(_build.PKG.parent / "tools"))
+    import asm_load_hazards
+    srcs = ["ekf_front.hip", "ekf_front_f64.hip", "ekf_cov_update.hip"]
+
+    def compile_one(name):
+        out = tmp_path / (name + ".s")
+        subprocess.run([_build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                        str(_build.CSRC / name), "-o", str(out)], check=True, capture_output=True)
+        return out
+
+    with ThreadPoolExecutor(max_workers=3) as pool:
+        outs = list(pool.map(compile_one, srcs))
+    for out in outs:
+        n_loads, hazards = asm_load_hazards.scan(str(out))
+        assert n_loads >= 700, (out.name, n_loads)
+        assert not hazards, (out.name, hazards[:3])

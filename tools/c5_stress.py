@@ -19,7 +19,7 @@ z = torch.tensor(np.stack([f[1][:, :3] for f in frames]), dtype=torch.float64, d
 
 
 def run(fused, ref=None):
-    f = EKF(INIT, max_landmarks=n, max_visible=m, cov_dtype="float32", fused=("force" if fused else False), quat_update="scalar_first")
+    f = EKF(INIT, max_landmarks=n, max_visible=m, cov_dtype="float32", fused=bool(fused), quat_update="scalar_first")
     for ids, poses in boot:
         f.observe(ids, poses)
     out = []
