@@ -1,36 +1,44 @@
-"""Trajectory text sink: same file format as the reference's
-``TrajectoryWriter`` (/root/reference/outputs/trajectory_writer.py:16-51).
+"""Camera-trajectory text sink.
 
-One line per frame: ``f"{ms/1000:.4f} x y z p3 p4 p5 p6"`` where ``p3..p6`` are
-``state[3:7]`` = qw qx qy qz (the reference's own comment calls this TUM order;
-it is not -- SURVEY appendix A, D8).  Numbers are written with ``str()`` of the
-array element, so the integer initial pose prints as ``0``/``1`` until the
-first marker has been added (D7).
+Interface and byte format are the contract of the reference's ``TrajectoryWriter``
+(/root/reference/outputs/trajectory_writer.py:16-51) as ``main/run_slam.py:110-125`` uses it:
+a context manager with ``write(timestamp_ms, pose)``; one line per frame,
+
+    <timestamp in seconds, 4 decimals> x y z qw qx qy qz
+
+The four values after the position are ``pose[3:7]`` in the filter's own order, scalar first (the
+reference labels the line "TUM"; TUM order would be qx qy qz qw -- SURVEY appendix A, D8).  Every
+number except the time stamp is written with ``str()`` of the array element: shortest round-trip
+repr for floats, and plain ``0`` / ``1`` for the integer initial pose that the filter hands out until
+the first marker has been added (D7).  ``tests/test_host_cpu.py`` pins the format on the reference's
+sample output.
 """
 from __future__ import annotations
 
-from pathlib import Path
+import contextlib
+import io
 
 
-class TrajectoryWriter:
+class TrajectoryWriter(contextlib.AbstractContextManager):
+    """``with TrajectoryWriter(path) as w: w.write(ms, pose)``.  Outside the ``with`` block (before
+    entering, after leaving) ``write`` is a no-op, as in the reference."""
+
     def __init__(self, filename: str) -> None:
-        self.file = None
         self.filename = filename
+        self._sink: io.TextIOBase | None = None
 
-    def __enter__(self):
-        self.file = Path(self.filename).open("w", encoding="utf-8")
+    def __enter__(self) -> "TrajectoryWriter":
+        self._sink = open(self.filename, "w", encoding="utf-8")
         return self
 
     def write(self, timestamp, pose) -> None:
-        quat = pose[3:]
-        seconds = timestamp / 1000
-        if self.file:
-            line = f"{seconds:.4f} "
-            line += f"{pose[0]} {pose[1]} {pose[2]} "
-            line += f"{quat[0]} {quat[1]} {quat[2]} {quat[3]}\n"
-            self.file.write(line)
+        if self._sink is None:
+            return
+        fields = [f"{timestamp / 1000:.4f}", *(str(pose[i]) for i in range(7))]
+        self._sink.write(" ".join(fields) + "\n")
 
-    def __exit__(self, exc_type, exc_value, traceback) -> None:
-        if self.file:
-            self.file.close()
-            self.file = None
+    def __exit__(self, *exc_info) -> None:
+        sink, self._sink = self._sink, None
+        if sink is not None:
+            sink.close()
+        return None

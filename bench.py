@@ -35,6 +35,7 @@ REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_PEAK_TFLOPS = {"float32": 157.3, "float64": 78.6}     # dense matrix peaks
 INIT_POSE = np.array([0, 0, 0, 1, 0, 0, 0, 0, 0, 0])
 
 
@@ -57,36 +58,63 @@ def parse_args():
 
 
 def cpu_baseline(n, m, frames):
-    """Reference-ops oracle on the same stream (seed 0): bootstrap untimed
-    (fast mode, same results), then `frames` timed steady-state updates."""
+    """CPU oracle on the same stream (seed 0), bootstrap untimed (fast mode, same results), then
+    timed steady-state updates, per BASELINE.md section 4:
+      * reference_ops (the reference's own op sequence) on all host threads  -> `value`
+      * reference_ops pinned to ONE thread (fewer frames: bounded sample)
+      * fast mode (rank-k update through BLAS) on all threads: separates the algorithmic speed-up
+        (2 N^3 -> 2 N^2 k) from the hardware one
+    Every leg reports mean, p10 and p90 of the per-frame times."""
+    import copy
     from aruco_slam_amd.synthetic import SyntheticStream
     from oracle.ekf_numpy import OracleEKF
     try:
-        from threadpoolctl import threadpool_info
+        from threadpoolctl import threadpool_info, threadpool_limits
         threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
+        threadpool_limits = None
         threads = os.cpu_count() or 1
     stream = SyntheticStream(n, m, seed=0)
     orc = OracleEKF(INIT_POSE, mode="fast")
     for ids, poses in stream.bootstrap():
         orc.observe(list(ids), poses)
-    orc.mode = "reference_ops"
-    cams, per = [], []
-    for ids, poses in stream.steady(frames):
-        t0 = time.perf_counter()
-        orc.observe(list(ids), poses)
-        per.append(time.perf_counter() - t0)
-        cams.append(np.asarray(orc.state[:7], dtype=np.float64).copy())
-    per = np.asarray(per)
-    steady = per[1:] if len(per) > 2 else per          # first frame pays allocator warm-up
+    steady_frames = [(list(ids), poses.copy()) for ids, poses in stream.steady(frames)]
+
+    def leg(mode, count, limit=None):
+        o = copy.deepcopy(orc)
+        o.mode = mode
+        per, cams = [], []
+        ctx = threadpool_limits(limits=limit) if (limit and threadpool_limits) else None
+        try:
+            for ids, poses in steady_frames[:count]:
+                t0 = time.perf_counter()
+                o.observe(ids, poses)
+                per.append(time.perf_counter() - t0)
+                cams.append(np.asarray(o.state[:7], dtype=np.float64).copy())
+        finally:
+            if ctx is not None:
+                ctx.restore_original_limits()
+        per = np.asarray(per)
+        st = per[1:] if len(per) > 2 else per            # first frame pays allocator warm-up
+        return {"updates_per_s": float(1.0 / st.mean()), "ms_per_update": float(1e3 * st.mean()),
+                "ms_p10": float(1e3 * np.percentile(st, 10)), "ms_p90": float(1e3 * np.percentile(st, 90)),
+                "frames_timed": int(len(st))}, np.stack(cams)
+
+    ref_all, cams = leg("reference_ops", frames)
+    one_frames = max(3, min(frames, 4))
+    ref_one, _ = leg("reference_ops", one_frames, limit=1) if threadpool_limits else ({"skipped": "threadpoolctl missing"}, None)
+    fast_all, _ = leg("fast", frames)
     return {
-        "value": float(1.0 / steady.mean()), "unit": "updates/s", "cores": int(threads),
+        "value": ref_all["updates_per_s"], "unit": "updates/s", "cores": int(threads),
         "kind": "port",
         "sample": (f"{frames} steady-state frames (first discarded) of the same n={n}, m={m} "
                    f"stream, NumPy/SciPy restatement in the reference's op sequence "
                    f"(dense Q, CSR of P, spsolve, dense (I-KH)P), host cpu_count={os.cpu_count()}"),
-        "ms_per_update": float(1e3 * steady.mean()),
-    }, np.stack(cams)
+        "ms_per_update": ref_all["ms_per_update"], "ms_p10": ref_all["ms_p10"], "ms_p90": ref_all["ms_p90"],
+        "one_core": dict(ref_one, cores=1, sample=f"{one_frames} frames, same op sequence, BLAS/OpenMP pools limited to 1 thread"),
+        "fast_mode": dict(fast_all, cores=int(threads),
+                          sample="same frames, rank-k update P - K(HP) through BLAS (2 N^2 k flops instead of 2 N^3)"),
+    }, cams
 
 
 def main():
@@ -195,18 +223,39 @@ def main():
 
     algo_bytes = 2.0 * dims * dims * elem                       # read P once, write once
     achieved = algo_bytes / (cov_us * 1e-6) / 1e9 if cov_us > 0 else 0.0
+    k = 3 * m
+    # everything else of the update (front kernel): SURVEY 8(d) "extra" bytes = support rows of P
+    # gathered for A = H P, the W panel written + read, the state
+    front_bytes = (10.0 + k) * dims * elem + 2.0 * dims * k * elem + 16.0 * dims
+    front_us = timing.get("front", timing.get("gather", (0.0, 0)))[0] if "front" in timing else \
+        sum(timing[name][0] for name in ("gather", "solve", "panel") if name in timing)
     # HBM bytes per launch from rocprofv3 PMC passes (tools/profile_round.sh +
     # tools/summarize_profile.py), and the rocprofv3 kernel-trace duration next to the
-    # HIP-event one (dispatch time stamps; they start a little before the first wave does)
-    traffic = rocprof_us = None
+    # HIP-event one (dispatch time stamps; they start a little before the first wave does).
+    # NOT measured in this run: constants from the committed profile named in traffic_source.
+    traffic = rocprof_us = traffic_src = None
     pmc = REPO / "profiles" / "cov_update_pmc_traffic.json"
     if pmc.exists():
         try:
             table = json.loads(pmc.read_text())
-            traffic = table.get(f"n{n}_m{m}_{args.cov_dtype}")
-            rocprof_us = table.get(f"n{n}_m{m}_{args.cov_dtype}_rocprof_mean_us")
+            key = f"n{n}_m{m}_{args.cov_dtype}"
+            traffic = table.get(key)
+            rocprof_us = table.get(key + "_rocprof_mean_us")
+            traffic_src = table.get(key + "_source")
         except Exception:
-            traffic = rocprof_us = None
+            traffic = rocprof_us = traffic_src = None
+    mfma_peak = MFMA_PEAK_TFLOPS[args.cov_dtype]
+    executed_flops = 1.0 * dims * dims * k                      # symmetric kernel: lower-triangle tiles only
+    secs = cov_us * 1e-6 if cov_us > 0 else float("inf")
+    # which roof bounds the kernel: algorithmic intensity k / sizeof(T) flop per byte against the ridge
+    # (157.3 TF / 8 TB/s = 19.7 for f32): C2 6, C3 24 (on the ridge: HBM), C5 48 (MFMA)
+    ridge = mfma_peak * 1e3 / HBM_PEAK_GBS
+    if k / elem > 1.5 * ridge:
+        algo_tf = 2.0 * dims * dims * k / secs / 1e12
+        rl_primary = {"bound": "mfma", "achieved": algo_tf, "peak": mfma_peak, "unit": "TFLOP/s", "frac": algo_tf / mfma_peak,
+                      "note": "algorithmic flops 2 N^2 k; the symmetric kernel EXECUTES N^2 k (see mfma_util), so frac may exceed 1"}
+    else:
+        rl_primary = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
     out = {
         "metric": "EKF updates/sec at n=1024 landmarks, m=32 obs/frame" if (n, m) == (1024, 32)
                   else f"EKF updates/sec at n={n} landmarks, m={m} obs/frame",
@@ -221,16 +270,37 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"n={n} landmarks, m={m} visible/frame, N={dims}, k={3 * m}, "
                                f"{args.cov_dtype} covariance, one independent sequence per GPU",
-                   "sequences": world, "cov_kernel": args.cov_kernel},
-        "roofline": {"bound": "hbm", "kernel": "ekf_cov_update (P <- P + Q - W^T W)",
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                   "sequences": world, "cov_kernel": args.cov_kernel,
+                   "front": "stage kernels" if args.unfused else "fused front kernel"},
+        "roofline": dict(rl_primary, **{
+                     "kernel": "ekf_cov_update (P <- P + Q - W^T W)",
+                     "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS},
+                     "traffic": traffic,
+                     "traffic_source": traffic_src and (traffic_src + " (rocprofv3 PMC passes of an earlier run of this "
+                                                        "command; not measured in this run)"),
                      "algorithmic_bytes_per_launch": algo_bytes,
                      "mean_launch_us": cov_us, "launches_timed": cov_launches,
+                     "timing": "HIP events attached to the dispatch (start/stop time stamps of the kernel itself)",
                      "rocprofv3_mean_us": rocprof_us,
-                     "flops_per_launch": 2.0 * dims * dims * 3 * m,
-                     "achieved_tflops": 2.0 * dims * dims * 3 * m / (cov_us * 1e-6) / 1e12
-                     if cov_us > 0 else 0.0},
+                     "residency": ("P is %.0f MB padded: it stays in the 256 MB Infinity Cache between frames, so "
+                                   "`achieved` is an algorithmic-bytes rate, not DRAM traffic" % (flt.backend.ld ** 2 * elem / 1e6))
+                                  if flt.backend.ld ** 2 * elem < 200e6 else
+                                  "P is %.0f MB padded: larger than the Infinity Cache, streamed from HBM" % (flt.backend.ld ** 2 * elem / 1e6),
+                     "algorithmic_flops_per_launch": 2.0 * dims * dims * k,
+                     "algorithmic_tflops": 2.0 * dims * dims * k / secs / 1e12,
+                     "executed_flops_per_launch": executed_flops,
+                     "mfma_util": executed_flops / secs / 1e12 / mfma_peak,
+                     "mfma_peak_tflops": mfma_peak,
+                     "front": {"kernel": "ekf_front_kernel (measurement model, S, Cholesky, W, dx, injection)"
+                                         if not args.unfused else "gather + solve + panel",
+                               "algorithmic_bytes_per_launch": front_bytes, "mean_launch_us": front_us,
+                               "timing": "HIP events recorded around the launch (includes the launch gap)",
+                               "achieved": front_bytes / (front_us * 1e-6) / 1e9 if front_us > 0 else 0.0,
+                               "frac": front_bytes / (front_us * 1e-6) / 1e9 / HBM_PEAK_GBS if front_us > 0 else 0.0,
+                               "bound": "latency (serial pivot chain of the k x k Cholesky on one workgroup)"},
+                     "whole_frame": {"algorithmic_bytes": algo_bytes + front_bytes,
+                                     "achieved": (algo_bytes + front_bytes) / (elapsed / k_steps) / 1e9,
+                                     "frac": (algo_bytes + front_bytes) / (elapsed / k_steps) / 1e9 / HBM_PEAK_GBS}}),
         "kernel_us": {name: round(us, 3) for name, (us, _) in timing.items()},
         "gather_ms": gather_ms,
         "host_boundary_updates_per_s": host_boundary,

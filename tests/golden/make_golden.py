@@ -22,6 +22,8 @@ Fixtures written (inputs + the reference's outputs, data only):
   g4_scale_n1024.npz         n=1024, m=32: bootstrap + 3 frames, checksums
   g6_quaternion_rule.npz     SciPy's behaviour at the call site :138-149
   c1_detections.npz          the synthetic C1 replay itself (inputs only)
+  g5_trajectory.txt, g5_map.txt, g5_detections.npz
+                             the same EKF_Rotations run driven like main/run_slam.py (``g5txt`` mode)
   g5_rotations.npz           EKF_Rotations (ekf_with_rotations.py): h/dh lambdas on 128 random
                              20-vectors, 120-frame 6-marker free run with full (state, P)
                              snapshots before/after 10 of its steps
@@ -109,6 +111,40 @@ def golden_rotations():
     print("g5 done")
 
 
+def golden_rotations_app_loop(traj_writer_cls):
+    """G5 text outputs: the SAME 120-frame sequence as g5_rotations.npz driven the way
+    main/run_slam.py:110-143 drives a tracker (observe only on frames with detections, get_poses
+    every frame, TrajectoryWriter line per frame, save_map at the end) with the reference's
+    EKF_Rotations -> g5_trajectory.txt, g5_map.txt, and the replay inputs g5_detections.npz."""
+    from filters.ekf_with_rotations import EKF_Rotations
+    flt = EKF_Rotations(np.array([0, 0, 0, 1, 0, 0, 0, 0, 0, 0]))
+    seq = small_sequence(frames=120, markers=6, max_visible=4, seed=3)
+    tmpdir = Path(tempfile.mkdtemp(prefix="g5txt_"))
+    cat_ids, cat_poses, offs, has, stamps = [], [], [0], [], []
+    with traj_writer_cls(str(tmpdir / "trajectory.txt")) as writer:
+        for ts, ids, poses in seq:
+            stamps.append(ts)
+            has.append(ids is not None)
+            if ids is not None:                            # base_filter.py:197-204
+                flt.observe(ids, poses)
+                cat_ids.append(ids)
+                cat_poses.append(poses)
+                offs.append(offs[-1] + len(ids))
+            else:
+                offs.append(offs[-1])
+            camera_pose, _ = flt.get_poses()               # base_filter.py:206-207
+            writer.write(ts, camera_pose)                  # run_slam.py:124-125
+    flt.save_map(str(tmpdir / "map.txt"))                  # run_slam.py:143
+    (HERE / "g5_trajectory.txt").write_text((tmpdir / "trajectory.txt").read_text())
+    (HERE / "g5_map.txt").write_text((tmpdir / "map.txt").read_text())
+    np.savez_compressed(HERE / "g5_detections.npz", ids=np.concatenate(cat_ids).astype(np.int32),
+                        poses=np.concatenate(cat_poses), offsets=np.asarray(offs, dtype=np.int64),
+                        timestamps_ms=np.asarray(stamps, dtype=np.float64), has_detections=np.asarray(has))
+    g5 = np.load(HERE / "g5_rotations.npz", allow_pickle=False)
+    assert np.array_equal(g5["final_state"], np.asarray(flt.state, dtype=np.float64)), "not the g5 run"
+    print("g5 app-loop outputs done")
+
+
 # Seed of the C1 replay.  The as-written reference is chaotic (SURVEY F5): a
 # 1e-15 input perturbation reaches 1e-4 within 100-200 frames for every seed
 # tried (0..15); seed 6 has the longest horizon.  The fixture therefore also
@@ -122,6 +158,9 @@ def main():
     ekf_cls, traj_writer_cls = load_reference()
     if len(sys.argv) > 1 and sys.argv[1] == "g5":
         golden_rotations()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "g5txt":
+        golden_rotations_app_loop(traj_writer_cls)
         return
     init_pose = np.array([0, 0, 0, 1, 0, 0, 0, 0, 0, 0])   # main/run_slam.py:85-88
 

@@ -16,13 +16,14 @@ from conftest import chaos_horizon, load_npz, rel_err, rel_err_elem, report
 pytestmark = pytest.mark.gpu
 
 INIT = np.array([0, 0, 0, 1, 0, 0, 0, 0, 0, 0])
-STEP_TOL = {"float64": 1e-10, "float32": 2e-5}
-# element-wise relative bound per teacher-forced step, |a-b| <= tol * max(|b|, 1e-3) for EVERY entry
-# (conftest.rel_err_elem; the norm-wise STEP_TOL above is an absolute bound on entries < 1).  Set from
-# the measured values (profiles/r02_parity_metrics.json): fp64 ~1e-11, fp32 covariance ~5e-4 on the
-# smallest covariance entries (1e-3 .. 1e-2 in magnitude, stored with 24-bit mantissas after a
-# rank-k downdate that cancels most of their magnitude).
-ELEM_TOL = {"float64": 1e-9, "float32": 5e-3}
+# Both bounds are set from what was MEASURED on MI355X (profiles/r02_parity_metrics.jsonl), with a
+# factor of ~4 of head-room, not from the 1e-4 of north_star:
+#   norm-wise  rel_err      = max|a-b| / max(1, max|b|)      (an absolute bound on entries < 1)
+#   element-wise rel_err_elem = max_i |a_i-b_i| / max(|b_i|, 1e-3)
+# measured per teacher-forced step: fp64 4e-15 / 6e-12; fp32 covariance 1e-7 / 1.3e-5 on (state, P)
+# (G2, G5), 6e-7 / 5.4e-5 on the n=1024 variances (G4), 6e-7 / 6e-6 at n=4096 (C5).
+STEP_TOL = {"float64": 1e-10, "float32": 2e-6}
+ELEM_TOL = {"float64": 1e-9, "float32": 2e-4}
 
 
 def _ekf(**kw):
@@ -118,7 +119,7 @@ def test_c1_teacher_forced_chain_all_200_frames(dtype, kernel):
     offs = det["offsets"]
     orc = _oracle(mode="fast")
     flt = _ekf(max_landmarks=16, max_visible=8, cov_dtype=dtype, cov_kernel=kernel)
-    worst_s = worst_p = 0.0
+    worst_s = worst_p = worst_e = 0.0
     for f in range(len(det["timestamps_ms"])):
         if not det["has_detections"][f]:
             continue
@@ -131,7 +132,10 @@ def test_c1_teacher_forced_chain_all_200_frames(dtype, kernel):
         flt.observe(ids, poses)
         worst_s = max(worst_s, rel_err(flt.state, orc.state))
         worst_p = max(worst_p, rel_err(flt.uncertainty, orc.uncertainty))
+        worst_e = max(worst_e, rel_err_elem(flt.state, orc.state), rel_err_elem(flt.uncertainty, orc.uncertainty))
+    report(f"c1_teacher_forced_chain[{dtype},{kernel}]", state_norm=worst_s, cov_norm=worst_p, elem=worst_e)
     assert worst_s <= STEP_TOL[dtype] and worst_p <= STEP_TOL[dtype], (worst_s, worst_p)
+    assert worst_e <= ELEM_TOL[dtype], worst_e
 
 
 def _replay_c1(flt):
@@ -193,7 +197,7 @@ def test_free_run_200_frames_scalar_first_convention(dtype, tol):
 
 @pytest.mark.parametrize("name,dtype,tol", [("g4_scale_n256.npz", "float64", 1e-8),
                                             ("g4_scale_n1024.npz", "float64", 1e-8),
-                                            ("g4_scale_n1024.npz", "float32", 1e-4)])
+                                            ("g4_scale_n1024.npz", "float32", 5e-6)])
 def test_g4_scale_vs_reference(name, dtype, tol):
     g = load_npz(name)
     n, m = int(g["n"]), int(g["m"])
@@ -221,7 +225,7 @@ def test_g4_scale_vs_reference(name, dtype, tol):
     assert worst[0] <= tol and worst[1] <= tol and worst[4] <= tol, worst
     # element-wise: state and variances (all well above the 1e-3 floor) to the same bound; sampled
     # off-diagonal blocks hold entries down to 1e-6, i.e. mostly the absolute floor
-    etol = {"float64": 1e-7, "float32": 5e-3}[dtype]
+    etol = {"float64": 1e-8, "float32": 2e-4}[dtype]
     assert worst[2] <= etol and worst[3] <= etol and worst[5] <= etol, worst
     assert np.array_equal(p, p.T)          # bitwise symmetric
 
@@ -392,6 +396,39 @@ def test_c1_run_slam_outputs_vs_reference_files(tmp_path, golden_dir):
     ri, rx, ru = _parse_map(ref_m)
     assert gi == ri and gx.shape == rx.shape and gu.shape == ru.shape
     assert np.isfinite(gx).all() and (gu > 0).all()
+
+
+def test_run_slam_ekf_rotations_outputs_vs_reference_files(tmp_path, golden_dir):
+    """f2 end to end: ``run_slam --filter ekf_rotations`` (main/run_slam.py:69-79, 110-143) on the
+    120-frame replay; trajectory.txt and map.txt against the files the reference's EKF_Rotations wrote for
+    the same frames (tests/golden/make_golden.py g5txt).  This filter uses the consistent quaternion
+    convention, so it is not chaotic and the WHOLE run is compared, map values included."""
+    import argparse
+    from aruco_slam_amd.main import run_slam
+    args = argparse.Namespace(video="input_video.mp4", filter="ekf_rotations",
+                              detections=str(golden_dir / "g5_detections.npz"), output_dir=str(tmp_path),
+                              filter_kwargs={"max_landmarks": 8, "max_visible": 6})
+    run_slam.main(args)
+    got_t, ref_t = (tmp_path / "trajectory.txt").read_text(), (golden_dir / "g5_trajectory.txt").read_text()
+    assert got_t.splitlines()[0] == ref_t.splitlines()[0] == "0.0333 0 0 0 1 0 0 0"
+    assert [ln.split()[0] for ln in got_t.splitlines()] == [ln.split()[0] for ln in ref_t.splitlines()]
+    a, b = _parse_traj(got_t), _parse_traj(ref_t)
+    assert a.shape == b.shape == (120, 8)
+    got_m, ref_m = (tmp_path / "map.txt").read_text(), (golden_dir / "g5_map.txt").read_text()
+    assert got_m.splitlines()[:4] == ref_m.splitlines()[:4]
+    lines_g, lines_r = got_m.splitlines()[4:], ref_m.splitlines()[4:]
+    assert len(lines_g) == len(lines_r)
+    ids_g = [int(lines_g[i]) for i in range(0, len(lines_g) - 2, 4)]
+    assert ids_g == [int(lines_r[i]) for i in range(0, len(lines_r) - 2, 4)]
+    num = lambda lines, off: np.array([[float(t) for t in lines[i + off].split(", ")]       # noqa: E731
+                                       for i in range(0, len(lines) - 2, 4)])
+    pose_g, pose_r, unc_g, unc_r = num(lines_g, 1), num(lines_r, 1), num(lines_g, 2), num(lines_r, 2)
+    assert pose_g.shape == pose_r.shape == (len(ids_g), 10) and unc_g.shape == unc_r.shape == (len(ids_g), 10)
+    errs = dict(traj_norm=rel_err(a, b), traj_elem=rel_err_elem(a, b), map_norm=rel_err(pose_g, pose_r),
+                map_elem=rel_err_elem(pose_g, pose_r), unc_norm=rel_err(unc_g, unc_r), unc_elem=rel_err_elem(unc_g, unc_r))
+    report("run_slam_ekf_rotations", **errs)
+    assert max(errs["traj_norm"], errs["map_norm"], errs["unc_norm"]) <= 1e-9, errs
+    assert max(errs["traj_elem"], errs["map_elem"], errs["unc_elem"]) <= 1e-6, errs
 
 
 def test_c1_map_txt_matches_reference_at_the_horizon(tmp_path, golden_dir):
@@ -703,12 +740,12 @@ def test_c5_full_size_properties_and_oracle_steps():
             cov_t = flt.backend.cov_t
             assert float(cov_t[dims:, :].abs().max()) == 0.0 and float(cov_t[:, dims:].abs().max()) == 0.0
             full = rel_err(p1, orc.uncertainty)
-            assert full <= 2e-5, full
+            assert full <= 5e-6, full
             del p1
     report("c5_oracle_steps[float32]", state_norm=worst[0], diag_norm=worst[1], state_elem=worst[2], diag_elem=worst[3],
            downdate_identity=ident, cov_norm_step1=full)
-    assert worst[0] <= 1e-4 and worst[1] <= 1e-4, worst
-    assert worst[2] <= 5e-3 and worst[3] <= 5e-3, worst
+    assert worst[0] <= 5e-6 and worst[1] <= 5e-6, worst          # measured 3e-9 / 6e-7
+    assert worst[2] <= 5e-5 and worst[3] <= 5e-5, worst          # measured 2e-7 / 6e-6
 
 
 @pytest.mark.parametrize("make,n,m,dtype", [(_ekf, 300, 20, "float32"), (_ekf, 128, 64, "float64"), (_rot, 40, 12, "float32")])

@@ -150,3 +150,29 @@ def test_g5_rotations_free_run_120_frames(mode):
     assert rel_err(np.stack(cams), g["cam"]) <= 1e-9
     assert rel_err(flt.state, g["final_state"]) <= 1e-9
     assert rel_err(flt.uncertainty, g["final_P"]) <= 1e-9
+
+
+def test_g5_rotations_app_loop_text_outputs(golden_dir):
+    """The oracle driven like main/run_slam.py reproduces the numbers of the reference's
+    EKF_Rotations trajectory.txt / map.txt (g5txt fixtures) over all 120 frames."""
+    from oracle.ekf_numpy import OracleEKFRotations
+    det = load_npz("g5_detections.npz")
+    offs = det["offsets"]
+    orc = OracleEKFRotations(INIT, mode="fast")
+    rows = []
+    for f in range(len(det["timestamps_ms"])):
+        if det["has_detections"][f]:
+            sl = slice(int(offs[f]), int(offs[f + 1]))
+            orc.observe(list(det["ids"][sl]), det["poses"][sl])
+        rows.append(np.asarray(orc.state[:7], dtype=np.float64))
+    ref = np.array([[float(t) for t in ln.split()] for ln in (golden_dir / "g5_trajectory.txt").read_text().splitlines()])
+    assert ref.shape == (120, 8)
+    assert np.abs(ref[:, 0] - np.round(det["timestamps_ms"] / 1000.0, 4)).max() <= 1e-12
+    assert rel_err(np.stack(rows), ref[:, 1:]) <= 1e-9
+    lines = (golden_dir / "g5_map.txt").read_text().splitlines()[4:]
+    ids = [int(lines[i]) for i in range(0, len(lines) - 2, 4)]
+    pose = np.array([[float(t) for t in lines[i + 1].split(", ")] for i in range(0, len(lines) - 2, 4)])
+    unc = np.array([[float(t) for t in lines[i + 2].split(", ")] for i in range(0, len(lines) - 2, 4)])
+    assert ids == [k for k, _ in sorted(orc.landmarks.items(), key=lambda kv: kv[1])]
+    assert rel_err(pose, orc.get_poses()[1]) <= 1e-9
+    assert rel_err(unc, orc.get_lm_uncertainties()) <= 1e-9

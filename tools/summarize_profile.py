@@ -26,6 +26,7 @@ ap.add_argument("src")
 ap.add_argument("tag")
 ap.add_argument("--key", default="n1024_m32_float32")
 ap.add_argument("--steady", type=int, default=100, help="launches at the end of the run to average")
+ap.add_argument("--parity", default=None, help="parity_metrics.jsonl of the same session to keep next to the profile")
 args = ap.parse_args()
 src, repo = Path(args.src), Path(__file__).resolve().parent.parent
 dst = repo / "profiles" / args.tag
@@ -48,8 +49,9 @@ for kind, name in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     pmc[name] = sum(vals[-args.steady:]) / len(vals[-args.steady:])
 traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
 cov_name = next(k for k in steady if "cov_update" in k)
+bench_args = (src / "bench_args.txt").read_text().strip() if (src / "bench_args.txt").exists() else "--cpu-frames 0 --steps 100 --warmup 10"
 summary = {
-    "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --cpu-frames 0 --steps 100 --warmup 10",
+    "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py " + bench_args,
     "steady_state_mean_us": {k: round(v, 3) for k, v in steady.items()},
     "cov_update": {"kernel": cov_name, "mean_us": round(steady[cov_name], 3),
                    "FETCH_SIZE_KiB": pmc["FETCH_SIZE"], "WRITE_SIZE_KiB": pmc["WRITE_SIZE"],
@@ -59,6 +61,8 @@ summary = {
 bench_line = (src / "trace.json").read_text().strip().splitlines()[-1]
 summary["bench_line_under_rocprof"] = json.loads(bench_line)
 (dst / "summary.json").write_text(json.dumps(summary, indent=1))
+if args.parity and Path(args.parity).exists():
+    shutil.copy(args.parity, dst / "parity_metrics.jsonl")
 tfile = repo / "profiles" / "cov_update_pmc_traffic.json"
 table = json.loads(tfile.read_text()) if tfile.exists() else {}
 table[args.key] = traffic
