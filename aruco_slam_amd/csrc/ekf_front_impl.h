@@ -413,77 +413,41 @@ __device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, int RS, doubl
     for (int b = 0; b < nb; ++b) {
         const int cb = EKF_RB * b;
         double* cur = colbuf(b);
-        if (b > 0) {
-            for (int i = b + wave; i <= nb; i += NW) {
-                SvAcc a;
-                sv_acc_load(a, cur, kp, i, c, g);
-                sv_term_lds(a, colbuf(b - 1), kp, i, b, c, g);
-                sv_acc_store(a, cur, kp, i, c, g);
-            }
-            __syncthreads();
-        }
+        double* dscr = dscr0 + (b & 1) * (16 * 17);
         EKF_STAMP();
-        const int nrows = kp - cb + 1;
-        const int nrw = (nrows > 64) ? (nrows - 64 + 47) / 48 : 0;
-        if (wave <= nrw + 1) {
-            const bool idw = (wave == nrw + 1);
-            int row;
-            if (wave == 0 || lane < EKF_RB) row = cb + lane;
-            else if (idw) row = -1;
-            else row = cb + 64 + 48 * (wave - 1) + (lane - EKF_RB);
-            const bool ident = idw && lane >= EKF_RB && lane < 2 * EKF_RB;
-            const bool live = !idw && (wave == 0 || lane >= EKF_RB) && row <= kp;
-            const double* src = cur + (size_t)min(max(row, 0), kp) * SV_CLD;
-            double a[EKF_RB];
+        if (wave == 0) {
+            // the diagonal block (the critical path): last left-looking term, 16-pivot chain as rank-1
+            // MFMA updates (ekf_solve_device.h), X = L_bb^-1 into LDS for the panel and the publication
+            SvDiag s;
+            s.m = sv_diag_load(cur, b, c, g);
+            if (b > 0) s.m = sv_diag_term(s.m, colbuf(b - 1), b, c, g);
+            if (fr.stamps && tid == 0 && b < 4) fr.stamps[47 + 2 * b] = clock64();
+            const int badnow = sv_diag_chain(s, c, g);
+            if (fr.stamps && tid == 0 && b < 4) fr.stamps[48 + 2 * b] = clock64();
+            if (badnow && !bad) badb = 100 + b;                                    // diagnostics: first bad block column
+            bad |= badnow;
+            sv_x_store(s.x, dscr, c, g);
+            if (fr.wdbg) {                               // dense L for tests only
 #pragma unroll
-            for (int x = 0; x < EKF_RB; ++x) a[x] = (row < 0) ? ((x == lane - EKF_RB) ? 1.0 : 0.0) : src[x];
-#pragma unroll
-            for (int j = 0; j < EKF_RB; ++j) {
-                const double d = ekf_readlane_f64(a[j], j);
-                bad |= !(d > 0.0);
-                const double y = ekf_rsqrt_f64(d);
-                const double lj = a[j] * y;
-                a[j] = lj;
-                // broadcasts first, updates second: back-to-back v_readlane into distinct scalar registers,
-                // no wait states between a broadcast and the fma that consumes it
-                double lx[EKF_RB];
-#pragma unroll
-                for (int x = j + 1; x < EKF_RB; ++x) lx[x] = ekf_readlane_f64(lj, x);
-#pragma unroll
-                for (int x = j + 1; x < EKF_RB; ++x) a[x] = __builtin_fma(-lj, lx[x], a[x]);
+                for (int r = 0; r < 4; ++r)
+                    fr.lmat[(size_t)(cb + c) * fr.ldl + cb + g + 4 * r] = (c >= g + 4 * r) ? s.lt[r] : 0.0;
             }
-            if (bad && !badb) badb = 100 + b;                                      // diagnostics: first bad block column
-            if (live) {
-                double* dst = cur + (size_t)row * SV_CLD;
-#pragma unroll
-                for (int x = 0; x < EKF_RB; ++x) dst[x] = a[x];
-                if (fr.wdbg && row < kp) {               // dense L for tests only
-#pragma unroll
-                    for (int x = 0; x < EKF_RB; ++x) fr.lmat[(size_t)row * fr.ldl + cb + x] = (cb + x <= row) ? a[x] : 0.0;
-                }
-            }
-            if (ident) {                                 // a[x] = Dinv_b[x][i], i = lane - 16
-                const int i = lane - EKF_RB;
-#pragma unroll
-                for (int x = 0; x < EKF_RB; ++x) dscr0[(b & 1) * (16 * 17) + x * 17 + i] = a[x];
-            }
+        } else if (wave == NW - 1) {
+            if (b > 0) publish(b - 1);                   // nothing else: write-through stores stay off the working waves
         } else {
-            const bool pubonly = NW - (nrw + 2) >= 3;           // wave NW-1 does nothing but publish
-            const int fw = wave - (nrw + 2), nfw = NW - (nrw + 2) - (pubonly ? 1 : 0);
-            if (b > 0 && wave == NW - 1) publish(b - 1);       // off the pivot chain's critical path
+            const int fw = wave - 1, nfw = NW - 2;       // free waves
             if (all_resident && b == 0 && nb > 1) {
-                // every remaining block column of S, by all non-pivot waves: they were written together
-                // with block column 0, so no polling (a straggler still reads as a sentinel -> retry path)
-                const int fw0 = wave - (nrw + 2), nfw0 = NW - (nrw + 2);
+                // every remaining block column of S: they were written together with block column 0, so
+                // no polling (a straggler still reads as a sentinel -> retry path)
                 int ntot2 = 0;
                 for (int tc = 1; tc < nb; ++tc) ntot2 += nb - tc + 1;
-                for (int base = fw0; base < ntot2; base += nfw0 * PB) {
+                for (int base = fw; base < ntot2; base += nfw * PB) {
                     sf64x4 v2[PB];
                     FrBlockSrc s2[PB];
                     int i2[PB], t2[PB];
 #pragma unroll
                     for (int j = 0; j < PB; ++j) {
-                        int u = base + nfw0 * j, tc = 1;
+                        int u = base + nfw * j, tc = 1;
                         const bool has = u < ntot2;
                         u = has ? u : 0;
                         while (u >= nb - tc + 1) { u -= nb - tc + 1; ++tc; }
@@ -509,9 +473,16 @@ __device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, int RS, doubl
                             fr_block_put(fr_block_settle(s2[j], v2[j], spin_fail), colbuf(t2[j]), kp, nb, i2[j], lane);
                 }
             }
-            if (pubonly && wave == NW - 1) {
-                // nothing else
-            } else {
+            // the blocks below the diagonal of THIS column: the one term that could not be applied earlier
+            if (fr.stamps && tid == 64 && b == 1) fr.stamps[56] = clock64();
+            if (b > 0)
+                for (int i = b + 1 + fw; i <= nb; i += nfw) {
+                    SvAcc a;
+                    sv_acc_load(a, cur, kp, i, c, g);
+                    sv_term_lds(a, colbuf(b - 1), kp, i, b, c, g);
+                    sv_acc_store(a, cur, kp, i, c, g);
+                }
+            if (fr.stamps && tid == 64 && b == 1) fr.stamps[57] = clock64();
             if (b >= 1 && b + 1 < nb)
                 for (int i = b + 1 + fw; i <= nb; i += nfw) {
                     SvAcc a;
@@ -519,6 +490,7 @@ __device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, int RS, doubl
                     sv_term_lds(a, colbuf(b - 1), kp, i, b + 1, c, g);
                     sv_acc_store(a, colbuf(b + 1), kp, i, c, g);
                 }
+            if (fr.stamps && tid == 64 && b == 1) fr.stamps[58] = clock64();
             const int tc = b + 2;
             if (tc < nb)
                 for (int i = tc + fw; i <= nb; i += nfw) {
@@ -539,11 +511,22 @@ __device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, int RS, doubl
                         sv_acc_store(a, colbuf(tc), kp, i, c, g);
                     }
                 }
+        }
+        if (fr.stamps && tid == 64 && b == 1) fr.stamps[59] = clock64();
+        __syncthreads();
+        EKF_STAMP();
+        // panel: L_ib = S'_ib X^T for every row block below the diagonal (the residual row rides along)
+        for (int i = b + 1 + wave; i <= nb; i += NW) {
+            sv_panel_block(cur, dscr, kp, i, c, g);
+            if (fr.wdbg && i < nb) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    fr.lmat[(size_t)(EKF_RB * i + g + 4 * r) * fr.ldl + cb + c] = cur[(size_t)(EKF_RB * i + g + 4 * r) * SV_CLD + c];
             }
         }
         __syncthreads();
-        EKF_STAMP();
     }
+    EKF_STAMP();
     if (wave == NW - 1) publish(nb - 1);
     if ((bad | spin_fail | stale) && lane == 0) {
         atomicOr(fr.status, (bad ? EKF_ST_NOT_SPD : 0) | (spin_fail ? EKF_ST_TIMEOUT : 0) | (stale ? EKF_ST_STALE_S : 0));
@@ -873,7 +856,7 @@ static void ekf_front_go(const EkfFrame& fr, hipStream_t s) {
     const int nb = fr.kpad / EKF_RB, nS = nb * (nb + 1) / 2;
     const size_t lds_s = ((size_t)fr.k * JC + NSLOT * 16 + 32 + fr.kpad) * 8 + 16;
     const size_t lds_c = ((size_t)fr.k * JC + (size_t)fr.kpad * FR_ALD) * 8 + 72 * 4 + 8 * 64 * 8 + 16;
-    const size_t lds_f = (size_t)ekf_solve_stream_lds_bytes(fr.kpad, fr.k) + 2 * 16 * 17 * 8;
+    const size_t lds_f = (size_t)ekf_solve_stream_lds_bytes(fr.kpad, fr.k);
     size_t lds = lds_s > lds_c ? lds_s : lds_c;
     if (lds_f > lds) lds = lds_f;
     hipLaunchKernelGGL((ekf_front_kernel<T, NU, MODEL, NB>), dim3(nS + 2 + fr.ncols / 64), dim3(FR_T), lds, s, fr,

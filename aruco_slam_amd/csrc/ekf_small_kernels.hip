@@ -188,7 +188,7 @@ template void ekf_launch_gather<double>(const EkfFrame&, hipStream_t);
 // number of block columns resident in LDS: all of them when they fit (kpad <= 128), else a ring
 int ekf_solve_stream_ring(int kpad, int k) {
     const size_t col = (size_t)(kpad + 1) * SV_CLD * sizeof(double);
-    const size_t fixed = (8 + 2 * 16 * 17) * sizeof(double);     // + Dinv scratch of the fused front kernel
+    const size_t fixed = (8 + 2 * 16 * 17) * sizeof(double);     // + X = L_bb^-1 scratch, two slots
     (void)k;
     int rs = (int)((160 * 1024 - fixed) / col);
     const int nb = kpad / EKF_RB;
@@ -196,7 +196,7 @@ int ekf_solve_stream_ring(int kpad, int k) {
     return rs < 4 ? 4 : rs;
 }
 int ekf_solve_stream_lds_bytes(int kpad, int k) {
-    return (int)(((size_t)ekf_solve_stream_ring(kpad, k) * (kpad + 1) * SV_CLD + 8) * sizeof(double));
+    return (int)(((size_t)ekf_solve_stream_ring(kpad, k) * (kpad + 1) * SV_CLD + 8 + 2 * 16 * 17) * sizeof(double));
 }
 
 __global__ __launch_bounds__(SV_T) void ekf_solve_stream_kernel(EkfFrame fr, int RS) {
@@ -206,6 +206,7 @@ __global__ __launch_bounds__(SV_T) void ekf_solve_stream_kernel(EkfFrame fr, int
     // RS block columns live in LDS: all of them (RS == nb) or a ring (column c in slot c % RS,
     // overwritten when column c + RS is built, i.e. during iteration c + RS - 2)
     double* ring = v_sm;                                         // [RS][rows][SV_CLD]
+    double* dscr0 = v_sm + (size_t)RS * rows * SV_CLD + 8;       // [2][16][17] X = L_bb^-1 of block column b (slot b & 1)
     const bool all_resident = RS >= nb;
     auto colbuf = [&](int col) { return ring + (size_t)(col % RS) * rows * SV_CLD; };
     constexpr int NW = SV_T / 64;
@@ -243,78 +244,51 @@ __global__ __launch_bounds__(SV_T) void ekf_solve_stream_kernel(EkfFrame fr, int
     __syncthreads();
     EKF_STAMP();
 
+    // emission of a finished block column (from its LDS copy): -L blocks and Dinv in MFMA-operand
+    // order, y, the plain Dinv; one wave
+    auto emit = [&](int pb) {
+        const double* colb = colbuf(pb);
+        const double* dscr = dscr0 + (pb & 1) * (16 * 17);
+        for (int i = pb + 1; i < nb; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                fr.lop[sv_lop_index(i, pb) + r * 64 + lane] =
+                    -colb[(size_t)(EKF_RB * i + (lane & 15)) * SV_CLD + (lane >> 4) + 4 * r];
+        if (lane < EKF_RB) fr.yvec[EKF_RB * pb + lane] = colb[(size_t)kp * SV_CLD + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            fr.dop[(size_t)(pb * 4 + r) * 64 + lane] = dscr[(lane & 15) * 17 + (lane >> 4) + 4 * r];
+            fr.dinv[(size_t)(EKF_RB * pb + g + 4 * r) * EKF_RB + c] = dscr[(g + 4 * r) * 17 + c];
+        }
+    };
     int bad = 0;
     for (int b = 0; b < nb; ++b) {
         const int cb = EKF_RB * b;
         double* cur = colbuf(b);
-        if (b > 0) {   // (A) the one term that could not be applied earlier
-            for (int i = b + wave; i <= nb; i += NW) {
-                SvAcc a;
-                sv_acc_load(a, cur, kp, i, c, g);
-                sv_term_lds(a, colbuf(b - 1), kp, i, b, c, g);
-                sv_acc_store(a, cur, kp, i, c, g);
-            }
-            __syncthreads();
-        }
-        EKF_STAMP();
-        // (B) roles.  rows of this block column: cb .. kp (kp = residual row)
-        const int nrows = kp - cb + 1;
-        const int nrw = (nrows > 64) ? (nrows - 64 + 47) / 48 : 0;   // extra row waves after wave 0
-        if (wave <= nrw + 1) {
-            // wave 0: rows cb..cb+63.  waves 1..nrw: lanes 0-15 the diagonal rows again (every wave
-            // needs the pivot rows in its own lanes), lanes 16-63 rows cb+64+48(w-1)...  wave nrw+1:
-            // diagonal rows + the rows of I_16: e_i -> row i of L_bb^-T = column i of Dinv_b.
-            const bool idw = (wave == nrw + 1);
-            int row;
-            if (wave == 0 || lane < EKF_RB) row = cb + lane;
-            else if (idw) row = -1;
-            else row = cb + 64 + 48 * (wave - 1) + (lane - EKF_RB);
-            const bool ident = idw && lane >= EKF_RB && lane < 2 * EKF_RB;
-            const bool live = !idw && (wave == 0 || lane >= EKF_RB) && row <= kp;
-            const double* src = cur + (size_t)min(max(row, 0), kp) * SV_CLD;
-            double a[EKF_RB];
+        double* dscr = dscr0 + (b & 1) * (16 * 17);
+        if (wave == 0) {
+            // the diagonal block: last left-looking term, 16-pivot chain, X = L_bb^-1 into LDS
+            SvDiag s;
+            s.m = sv_diag_load(cur, b, c, g);
+            if (b > 0) s.m = sv_diag_term(s.m, colbuf(b - 1), b, c, g);
+            bad |= sv_diag_chain(s, c, g);
+            sv_x_store(s.x, dscr, c, g);
+            if (fr.wdbg) {                               // dense L for tests only
 #pragma unroll
-            for (int x = 0; x < EKF_RB; ++x) a[x] = (row < 0) ? ((x == lane - EKF_RB) ? 1.0 : 0.0) : src[x];
-#pragma unroll
-            for (int j = 0; j < EKF_RB; ++j) {
-                const double d = ekf_readlane_f64(a[j], j);
-                bad |= !(d > 0.0);
-                const double y = ekf_rsqrt_f64(d);
-                const double lj = a[j] * y;
-                a[j] = lj;
-#pragma unroll
-                for (int x = j + 1; x < EKF_RB; ++x) {
-                    const double lx = ekf_readlane_f64(lj, x);
-                    a[x] = __builtin_fma(-lj, lx, a[x]);
-                }
-            }
-            if (live) {
-                double* dst = cur + (size_t)row * SV_CLD;
-#pragma unroll
-                for (int x = 0; x < EKF_RB; ++x) dst[x] = a[x];
-                if (row == kp) {                         // residual row: y of this block
-#pragma unroll
-                    for (int x = 0; x < EKF_RB; ++x) fr.yvec[cb + x] = a[x];
-                } else if (row >= cb + EKF_RB) {         // -L block (row/16, b) in MFMA operand order
-                    const size_t base = sv_lop_index(row >> 4, b) + (row & 15);
-#pragma unroll
-                    for (int x = 0; x < EKF_RB; ++x) fr.lop[base + (x >> 2) * 64 + 16 * (x & 3)] = -a[x];
-                }
-                if (fr.wdbg && row < kp) {               // dense L for tests only
-#pragma unroll
-                    for (int x = 0; x < EKF_RB; ++x) fr.lmat[(size_t)row * fr.ldl + cb + x] = (cb + x <= row) ? a[x] : 0.0;
-                }
-            }
-            if (ident) {                                 // a[x] = Dinv_b[x][i], i = lane - 16
-                const int i = lane - EKF_RB;
-#pragma unroll
-                for (int x = 0; x < EKF_RB; ++x) {
-                    fr.dinv[(size_t)(cb + x) * EKF_RB + i] = a[x];
-                    fr.dop[(size_t)(b * 4 + (i >> 2)) * 64 + x + 16 * (i & 3)] = a[x];
-                }
+                for (int r = 0; r < 4; ++r)
+                    fr.lmat[(size_t)(cb + c) * fr.ldl + cb + g + 4 * r] = (c >= g + 4 * r) ? s.lt[r] : 0.0;
             }
         } else {
-            const int fw = wave - (nrw + 2), nfw = NW - (nrw + 2);   // free waves
+            const int fw = wave - 1, nfw = NW - 1;       // free waves
+            // the blocks below the diagonal of THIS column: the one term that could not be applied earlier
+            if (b > 0)
+                for (int i = b + 1 + fw; i <= nb; i += nfw) {
+                    SvAcc a;
+                    sv_acc_load(a, cur, kp, i, c, g);
+                    sv_term_lds(a, colbuf(b - 1), kp, i, b, c, g);
+                    sv_acc_store(a, cur, kp, i, c, g);
+                }
+            if (b > 0 && wave == NW - 1) emit(b - 1);
             // block column b+1: the q = b-1 term (operands still in LDS)
             if (b >= 1 && b + 1 < nb)
                 for (int i = b + 1 + fw; i <= nb; i += nfw) {
@@ -343,8 +317,20 @@ __global__ __launch_bounds__(SV_T) void ekf_solve_stream_kernel(EkfFrame fr, int
         }
         __syncthreads();
         EKF_STAMP();
+        // panel: L_ib = S'_ib X^T for every row block below the diagonal (the residual row rides along)
+        for (int i = b + 1 + wave; i <= nb; i += NW) {
+            sv_panel_block(cur, dscr, kp, i, c, g);
+            if (fr.wdbg && i < nb) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    fr.lmat[(size_t)(EKF_RB * i + g + 4 * r) * fr.ldl + cb + c] = cur[(size_t)(EKF_RB * i + g + 4 * r) * SV_CLD + c];
+            }
+        }
+        __syncthreads();
+        EKF_STAMP();
     }
-    if (bad && lane == 0) atomicOr(fr.status, 1);
+    if (wave == NW - 1) emit(nb - 1);
+    if (bad && lane == 0) atomicOr(fr.status, EKF_ST_NOT_SPD);
     EKF_STAMP();
 #undef EKF_STAMP
 }
