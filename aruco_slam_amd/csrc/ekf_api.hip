@@ -62,7 +62,7 @@ Layout make_layout(const ekf_config& c) {
     L.off_y = take((size_t)L.kmax * 8);
     L.off_lmcol = take((size_t)c.max_visible * 4);
     L.off_amat = take((size_t)L.kmax * L.cap * 8);
-    L.off_sblk = take((size_t)(L.kmax / EKF_RB) * L.kmax * 16 * 8);
+    L.off_sblk = take((size_t)(L.kmax / EKF_RB) * (L.kmax / EKF_RB + 1) / 2 * 256 * 8);
     L.off_lmat = take((size_t)L.kmax * L.kmax * 8);
     L.off_dinv = take((size_t)L.kmax * EKF_RB * 8);
     {
@@ -88,8 +88,8 @@ Layout make_layout(const ekf_config& c) {
         L.xl_y = L.xl_dop + nb * 256;
         L.xl_jac = L.xl_y + L.kmax;
         L.xl_tag = L.xl_jac + (size_t)L.kmax * EKF_JLD;
-        L.xl_xs = L.xl_tag + 32;                          // S blocks, layout of sblk ([block column][kmax][16])
-        L.xl_xr = L.xl_xs + nb * L.kmax * 16;             // residual
+        L.xl_xs = L.xl_tag + 32;                          // S blocks, layout of sblk (block (i, tc) at (i (i + 1) / 2 + tc) * 256)
+        L.xl_xr = L.xl_xs + nb * (nb + 1) / 2 * 256;      // residual
         L.xl_stag = L.xl_xr + (size_t)round_up(L.kmax, 16);   // S-block tags [16 tc + i]
         L.xl_len = L.xl_stag + 256;
         L.off_xl = take(2 * L.xl_len * 8);

@@ -150,13 +150,13 @@ __device__ __forceinline__ void fr_role_sblock(const EkfFrame& fr, int sb, int n
         }
     }
     __syncthreads();
+    double v = 0.0;
     if (tid < 256) {
         const int i = tid >> 4, c2 = tid & 15, r1 = 16 * bi + i, r2 = 16 * bj + c2;
-        double v;
         if (r1 >= k || r2 >= k) {
             v = (r1 == r2) ? 1.0 : 0.0;
         } else if (r2 > r1) {
-            v = 0.0;
+            v = 0.0;                                   // strict upper part of a diagonal block: mirrored on emission
         } else {
             const double* h1 = hs + r1 * JC;
             const int s1 = EKF_CAM + LMD * (r1 / RD - j0);
@@ -167,7 +167,12 @@ __device__ __forceinline__ void fr_role_sblock(const EkfFrame& fr, int sb, int n
             for (int d = 0; d < LMD; ++d) acc = __builtin_fma(h1[EKF_CAM + d], us[(s1 + d) * 16 + c2], acc);
             v = acc;
         }
-        ekf_stc(fr.xs + ((size_t)bj * fr.sblk_rows + r1) * 16 + c2, v);
+    }
+    __syncthreads();                                   // `us` is free: it becomes the block's tile
+    if (tid < 256) us[(tid >> 4) * 17 + (tid & 15)] = v;
+    __syncthreads();
+    if (tid < 64) {                                    // OP memory order, two 1 KB write-through stores
+        sv_sblock_emit<true>(fr.xs + sv_blk_index(bi, bj), us, bi == bj, tid);
         if (tid == 0) ekf_stc(fr.xs_tag + 16 * bj + bi, fr.seqno);
     }
     if (fr.stamps && sb == nS - 1 && tid == 0) fr.stamps[61] = wall_clock64();
@@ -213,331 +218,136 @@ __device__ __forceinline__ void fr_role_measure(const EkfFrame& fr, double* sm) 
 }
 
 // ---------------------------------------------------------------------------------------------
-// role: factorisation (the stand-alone solve kernel with exchange-buffer input / output)
+// role: factorisation = the shared register-resident Cholesky (ekf_solve_device.h: sv_factor) with the
+// exchange buffer as input and output
 // ---------------------------------------------------------------------------------------------
-// One 16x16 block of S (row block i of block column tc; i == nb: the residual row) travels from the
-// exchange buffer into the factor's LDS column buffer.  Lane <-> word mapping: word x*64 + lane of the
-// 2 KB block, i.e. row 4x + (lane >> 4), column lane & 15: every load / re-arm store instruction
-// covers 512 contiguous bytes.  Polling touches ONE word (the block's last); the bulk goes through
-// cacheable loads (sc1 stores are written through, see tools/xcd_exchange_probe.hip; nothing in this
-// launch has touched those lines before; whatever has not landed yet still reads as a sentinel and
-// is re-read coherently).
-// (the residual "block" is 16 words: lanes read it as words 2 (lane & 7), +1, twice -- the same two
-// 16-byte loads as for an S block, so the issue path has no divergent branch)
-struct FrBlockSrc { const double* p0; const double* p1; const double* w; const double* tag; };
-__device__ __forceinline__ FrBlockSrc fr_block_src(const EkfFrame& fr, int nb, int i, int tc, int lane) {
-    FrBlockSrc s;
-    if (i < nb) {
-        const double* base = fr.xs + ((size_t)tc * fr.sblk_rows + EKF_RB * i) * 16;
-        s.p0 = base + 2 * lane;
-        s.p1 = base + 128 + 2 * lane;
-        s.w = base + 255;
-        s.tag = fr.xs_tag + 16 * tc + i;
-    } else {
-        const double* base = fr.xr + EKF_RB * tc;
-        s.p0 = base + 2 * (lane & 7);
-        s.p1 = s.p0;
-        s.w = base + 15;
-        s.tag = fr.xl + fr.xl_tag + 16;
-    }
-    return s;
-}
-// Lane <-> word mapping of a 2 KB block: words 128 x + 2 lane, +1 (x = 0, 1), i.e. row 8x + (lane >> 3),
-// columns 2 (lane & 7), +1.  All exchange reads are coherent (sc1) loads; their cost is per instruction
-// (~400 cycles each when eight waves fetch at once), so the bulk uses 16-byte loads, written as inline asm
-// (the atomic builtins stop at 8 bytes): issue with fr_block_issue, then ONE fr_block_arrive for the
-// whole batch before the values are used.  Retries use the 8-byte builtin.  The block's frame tag travels
-// with the bulk (one more load in the same batch).
-// (tools/asm_load_hazards.py checks the generated code: nothing may touch the destination registers of
-// these loads between the issue and the wait -- the compiler does not know that they are in flight.)
-typedef double fr_d2 __attribute__((ext_vector_type(2)));
-struct FrBlockRaw { fr_d2 a, b; double t; };
-__device__ __forceinline__ void fr_block_issue(FrBlockRaw& r, const FrBlockSrc& s) {
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r.a) : "v"(s.p0) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r.b) : "v"(s.p1) : "memory");
-    asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(r.t) : "v"(s.tag) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void fr_block_arrive(FrBlockRaw (&r)[N]) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int j = 0; j < N; ++j) asm volatile("" : "+v"(r[j].a), "+v"(r[j].b), "+v"(r[j].t));       // uses stay below the wait
-}
-__device__ __forceinline__ sf64x4 fr_block_value(const FrBlockRaw& r) { return sf64x4{r.a[0], r.a[1], r.b[0], r.b[1]}; }
-// a tag that has not landed yet proves nothing; one that HAS landed must be this frame's
+// IO policy.  Input: the wave's S blocks (OP memory order, 2 KB each: two 16-byte coherent loads per
+// lane, ekf_ldc16 -- the atomic builtins stop at 8 bytes) and, for the wave that owns the residual
+// row, z - h.  Polling touches ONE word per row (the last word of the row's first block: the S-block
+// workgroups all finish at about the same time); correctness does not depend on it: every word is
+// checked against the sentinel after the bulk has arrived and fetched again until it has landed.
+// Output: Dinv_b (`dop` order), -L blocks (`lop` order), y, the frame tags -- write-through stores,
+// straight from the registers (both orders ARE the OP layout).
 __device__ __forceinline__ int fr_tag_stale(double tag, double seqno) { return !ekf_is_sent(tag) && tag != seqno; }
-__device__ __forceinline__ sf64x4 fr_block_load_coherent(const FrBlockSrc& s) {
-    return sf64x4{ekf_ldc(s.p0), ekf_ldc(s.p0 + 1), ekf_ldc(s.p1), ekf_ldc(s.p1 + 1)};
-}
-__device__ __forceinline__ bool fr_block_pending(const sf64x4& v) {
-    const bool p = ekf_is_sent(v[0]) || ekf_is_sent(v[1]) || ekf_is_sent(v[2]) || ekf_is_sent(v[3]);
-    return __any(p);
-}
-// one word of the block, same address in every lane: has the producer's store landed?
-__device__ __forceinline__ bool fr_block_landed(const FrBlockSrc& s) { return !ekf_is_sent(ekf_ldc(s.w)); }
-__device__ __forceinline__ void fr_block_wait(const FrBlockSrc& s, int& spin_fail) {
-    int it = 0;
-    while (!fr_block_landed(s)) {
-        if (++it > EKF_SPIN_MAX) { spin_fail = 1; break; }
-        ekf_poll_sleep();
+struct SvIoFused {
+    const EkfFrame& fr;
+    int spin_fail, stale;
+    __device__ __forceinline__ bool settled(const sf64x4& v) const {
+        return !__any(ekf_is_sent(v[0]) || ekf_is_sent(v[1]) || ekf_is_sent(v[2]) || ekf_is_sent(v[3]));
     }
-}
-// the block's values are in `v` (first attempt); every word that still reads as the sentinel is fetched again
-__device__ __forceinline__ sf64x4 fr_block_settle(const FrBlockSrc& s, sf64x4 v, int& spin_fail) {
-    int it = 0;
-    while (fr_block_pending(v)) {
-        if (++it > EKF_SPIN_MAX) { spin_fail = 1; break; }
-        ekf_poll_sleep();
-        v = fr_block_load_coherent(s);
-    }
-    return v;
-}
-// single block (ring mode): bulk + tag, settled
-__device__ __forceinline__ sf64x4 fr_block_take(const FrBlockSrc& s, double seqno, int& spin_fail, int& stale) {
-    FrBlockRaw r[1];
-    fr_block_issue(r[0], s);
-    fr_block_arrive(r);
-    stale |= fr_tag_stale(r[0].t, seqno);
-    return fr_block_settle(s, fr_block_value(r[0]), spin_fail);
-}
-__device__ __forceinline__ void fr_block_put(const sf64x4& v, double* tgt, int kp, int nb, int i, int lane) {
-    const fr_d2 a = {v[0], v[1]}, b = {v[2], v[3]};
-    if (i < nb) {
-        *reinterpret_cast<fr_d2*>(tgt + (EKF_RB * i + (lane >> 3)) * SV_CLD + 2 * (lane & 7)) = a;
-        *reinterpret_cast<fr_d2*>(tgt + (EKF_RB * i + 8 + (lane >> 3)) * SV_CLD + 2 * (lane & 7)) = b;
-    } else if (lane < 8) {
-        *reinterpret_cast<fr_d2*>(tgt + kp * SV_CLD + 2 * lane) = a;
-    }
-}
-
-__device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, int RS, double* v_sm) {
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
-    const int kp = fr.kpad, nb = kp / EKF_RB, rows = kp + 1;
-    double* ring = v_sm;                                         // [RS][rows][SV_CLD]
-    double* dscr0 = v_sm + (size_t)RS * rows * SV_CLD + 8;       // [2][16][17] Dinv of block column b (slot b & 1)
-    const bool all_resident = RS >= nb;
-    auto colbuf = [&](int col) { return ring + (size_t)(col % RS) * rows * SV_CLD; };
-    constexpr int NW = FR_T / 64;
-    double* __restrict__ xlop = fr.xl;
-    double* __restrict__ xdop = fr.xl + fr.xl_dop;
-    double* __restrict__ xy = fr.xl + fr.xl_y;
-    int nstamp = 0, spin_fail = 0, stale = 0;
-#define EKF_STAMP() do { if (fr.stamps && tid == 0) fr.stamps[nstamp] = clock64(); ++nstamp; } while (0)
-    if (fr.stamps && tid == 0) fr.stamps[62] = wall_clock64();
-    EKF_STAMP();
-    constexpr int PB = 4;       // (small on purpose: this code runs once per launch, i.e. from a cold instruction cache)
-    // block columns brought into LDS before the first pivot chain: only column 0 when all columns stay
-    // resident (the others arrive during iteration 0, whose free waves have nothing else to do; later
-    // iterations have no slack for memory round trips), else 0 and 1 (column c >= 2 then arrives
-    // during iteration c - 2)
-    const int ncol0 = all_resident ? 1 : (nb > 1 ? 2 : 1);
-    int ntot = 0;
-    for (int tc = 0; tc < ncol0; ++tc) ntot += nb - tc + 1;
-    sf64x4 pv[PB];
-    FrBlockSrc ps[PB];
-    int pi[PB], ptc[PB];
-#pragma unroll
-    for (int j = 0; j < PB; ++j) {
-        int u = wave + NW * j, tc = 0;
-        const bool has = u < ntot;
-        u = has ? u : 0;
-        while (u >= nb - tc + 1) { u -= nb - tc + 1; ++tc; }
-        pi[j] = has ? tc + u : -1;
-        ptc[j] = tc;
-        ps[j] = fr_block_src(fr, nb, tc + u, tc, lane);
-    }
-    EKF_STAMP();
-    {   // poll one word per block, all blocks of this wave together
+    __device__ __forceinline__ void settle_block(sf64x4& v, int i, int tc, int lane) {
+        const double* base = fr.xs + sv_blk_index(i, tc);
         int it = 0;
-        for (;;) {
-            bool pend = false;
-#pragma unroll
-            for (int j = 0; j < PB; ++j)
-                if (pi[j] >= 0) pend = pend | !fr_block_landed(ps[j]);      // (no short circuit: loads together)
-            if (!pend) break;
+        while (!settled(v)) {
             if (++it > EKF_SPIN_MAX) { spin_fail = 1; break; }
             ekf_poll_sleep();
+            v = sf64x4{ekf_ldc(base + 2 * lane), ekf_ldc(base + 2 * lane + 1), ekf_ldc(base + 128 + 2 * lane),
+                       ekf_ldc(base + 129 + 2 * lane)};
         }
     }
-    {
-        FrBlockRaw raw[PB];
+    __device__ __forceinline__ sf64x4 fetch_resid(int tc, int g) {
+        const double* base = fr.xr + EKF_RB * tc + g;
+        sf64x4 v = {ekf_ldc(base), ekf_ldc(base + 4), ekf_ldc(base + 8), ekf_ldc(base + 12)};
+        int it = 0;
+        while (!settled(v)) {
+            if (++it > EKF_SPIN_MAX) { spin_fail = 1; break; }
+            ekf_poll_sleep();
+            v = sf64x4{ekf_ldc(base), ekf_ldc(base + 4), ekf_ldc(base + 8), ekf_ldc(base + 12)};
+        }
+        return v;
+    }
+    template <int NB, int N0, int N1>
+    __device__ __forceinline__ void load_all(sf64x4 (&z0)[N0], sf64x4 (&z1)[N1], int i0, int i1, bool has0, bool has1,
+                                             int lane, int g) {
+        const bool blk0 = has0 && i0 < NB, blk1 = has1 && i1 < NB;       // S-block rows (not the residual)
+        {   // one polled word per row of the wave
+            const double* w0 = blk0 ? fr.xs + sv_blk_index(i0, 0) + 255 : fr.xr + 15;
+            const double* w1 = blk1 ? fr.xs + sv_blk_index(i1, 0) + 255 : w0;
+            int it = 0;
+            if (has0)
+                for (;;) {
+                    const bool pend = (int)ekf_is_sent(ekf_ldc(w0)) | (int)ekf_is_sent(ekf_ldc(w1));       // (no short circuit: loads together)
+                    if (!pend) break;
+                    if (++it > EKF_SPIN_MAX) { spin_fail = 1; break; }
+                    ekf_poll_sleep();
+                }
+        }
+        // frame tags of the blocks (compiler-visible loads, issued before -- hence older than -- the bulk)
+        double t0[N0], t1[N1];
 #pragma unroll
-        for (int j = 0; j < PB; ++j)
-            if (pi[j] >= 0) fr_block_issue(raw[j], ps[j]);
-        fr_block_arrive(raw);
+        for (int tc = 0; tc < N0; ++tc) t0[tc] = (blk0 && tc <= i0) ? ekf_ldc(fr.xs_tag + 16 * tc + i0) : fr.seqno;
 #pragma unroll
-        for (int j = 0; j < PB; ++j) {
-            pv[j] = fr_block_value(raw[j]);
-            if (pi[j] >= 0) stale |= fr_tag_stale(raw[j].t, fr.seqno);
+        for (int tc = 0; tc < N1; ++tc) t1[tc] = (blk1 && tc <= i1) ? ekf_ldc(fr.xs_tag + 16 * tc + i1) : fr.seqno;
+#pragma unroll
+        for (int tc = 0; tc < N0; ++tc)
+            if (blk0 && tc <= i0) {
+                const double* p0 = fr.xs + sv_blk_index(i0, tc) + 2 * lane;
+                const sv_d2 a = ekf_ldc16(p0), b = ekf_ldc16(p0 + 128);
+                z0[tc] = sf64x4{a[0], a[1], b[0], b[1]};
+            }
+#pragma unroll
+        for (int tc = 0; tc < N1; ++tc)
+            if (blk1 && tc <= i1) {
+                const double* p0 = fr.xs + sv_blk_index(i1, tc) + 2 * lane;
+                const sv_d2 a = ekf_ldc16(p0), b = ekf_ldc16(p0 + 128);
+                z1[tc] = sf64x4{a[0], a[1], b[0], b[1]};
+            }
+#pragma unroll
+        for (int tc = 0; tc < N0; ++tc)
+            if (blk0 && tc <= i0) {
+                settle_block(z0[tc], i0, tc, lane);
+                stale |= fr_tag_stale(t0[tc], fr.seqno);
+            }
+#pragma unroll
+        for (int tc = 0; tc < N1; ++tc)
+            if (blk1 && tc <= i1) {
+                settle_block(z1[tc], i1, tc, lane);
+                stale |= fr_tag_stale(t1[tc], fr.seqno);
+            }
+        // the residual row (one wave): z - h, replicated in all 16 rows of its "block"
+        if (has0 && i0 == NB) {
+#pragma unroll
+            for (int tc = 0; tc < N0; ++tc)
+                if (tc < NB) z0[tc] = fetch_resid(tc, g);
+            stale |= fr_tag_stale(ekf_ldc(fr.xl + fr.xl_tag + 16), fr.seqno);
+        }
+        if (has1 && i1 == NB) {
+#pragma unroll
+            for (int tc = 0; tc < N1; ++tc)
+                if (tc < NB) z1[tc] = fetch_resid(tc, g);
+            stale |= fr_tag_stale(ekf_ldc(fr.xl + fr.xl_tag + 16), fr.seqno);
         }
     }
+    __device__ __forceinline__ void put_dinv(int b, const sf64x4& xop, int lane) {
+        double* xdop = fr.xl + fr.xl_dop;
 #pragma unroll
-    for (int j = 0; j < PB; ++j)
-        if (pi[j] >= 0) {
-            pv[j] = fr_block_settle(ps[j], pv[j], spin_fail);
-            fr_block_put(pv[j], colbuf(ptc[j]), kp, nb, pi[j], lane);
-        }
-    for (int u0 = wave + NW * PB; u0 < ntot; u0 += NW) {
-        int u = u0, tc = 0;
-        while (u >= nb - tc + 1) { u -= nb - tc + 1; ++tc; }
-        const FrBlockSrc s = fr_block_src(fr, nb, tc + u, tc, lane);
-        fr_block_wait(s, spin_fail);
-        fr_block_put(fr_block_take(s, fr.seqno, spin_fail, stale), colbuf(tc), kp, nb, tc + u, lane);
+        for (int r = 0; r < 4; ++r) ekf_stc(xdop + (size_t)(b * 4 + r) * 64 + lane, xop[r]);     // (the chunks poll the last word)
+        if (lane == 0) ekf_stc(fr.xl + fr.xl_tag + 1 + b, fr.seqno);
     }
-    __syncthreads();
-    EKF_STAMP();
+    __device__ __forceinline__ void put_l(int i, int b, const sf64x4& y, int lane) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ekf_stc(fr.xl + sv_lop_index(i, b) + r * 64 + lane, -y[r]);
+    }
+    __device__ __forceinline__ void put_y(int b, double yv, int c, bool active) {
+        if (active) ekf_stc(fr.xl + fr.xl_y + EKF_RB * b + c, yv);        // one instruction: a whole cache line
+    }
+};
 
-    // Publication of a finished block column (MFMA operand order, see ekf_kernels.h) by ONE wave
-    // that is not on the pivot chain's critical path, from the LDS copy: 512 contiguous bytes per
-    // store instruction, Dinv last (its last 512 bytes are what the chunks poll).
-    auto publish = [&](int pb) {
-        const double* colb = colbuf(pb);
-        const double* dscr = dscr0 + (pb & 1) * (16 * 17);
-        double dv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dv[r] = dscr[(lane & 15) * 17 + (lane >> 4) + 4 * r];
-        for (int i = pb + 1; i < nb; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                ekf_stc(xlop + sv_lop_index(i, pb) + r * 64 + lane,
-                        -colb[(size_t)(EKF_RB * i + (lane & 15)) * SV_CLD + (lane >> 4) + 4 * r]);
-        if (lane < EKF_RB) ekf_stc(xy + EKF_RB * pb + lane, colb[(size_t)kp * SV_CLD + lane]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            ekf_stc(xdop + (size_t)(pb * 4 + r) * 64 + lane, dv[r]);
-        if (lane == 0) ekf_stc(fr.xl + fr.xl_tag + 1 + pb, fr.seqno);
-        // ring mode: this workgroup reads the column back later (sv_terms_glb): be done before the barrier
-        if (!all_resident) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-    int bad = 0, badb = 0;
-    for (int b = 0; b < nb; ++b) {
-        const int cb = EKF_RB * b;
-        double* cur = colbuf(b);
-        double* dscr = dscr0 + (b & 1) * (16 * 17);
-        EKF_STAMP();
-        if (wave == 0) {
-            // the diagonal block (the critical path): last left-looking term, 16-pivot chain as rank-1
-            // MFMA updates (ekf_solve_device.h), X = L_bb^-1 into LDS for the panel and the publication
-            SvDiag s;
-            s.m = sv_diag_load(cur, b, c, g);
-            if (b > 0) s.m = sv_diag_term(s.m, colbuf(b - 1), b, c, g);
-            if (fr.stamps && tid == 0 && b < 4) fr.stamps[47 + 2 * b] = clock64();
-            const int badnow = sv_diag_chain(s, c, g);
-            if (fr.stamps && tid == 0 && b < 4) fr.stamps[48 + 2 * b] = clock64();
-            if (badnow && !bad) badb = 100 + b;                                    // diagnostics: first bad block column
-            bad |= badnow;
-            sv_x_store(s.x, dscr, c, g);
-            if (fr.wdbg) {                               // dense L for tests only
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    fr.lmat[(size_t)(cb + c) * fr.ldl + cb + g + 4 * r] = (c >= g + 4 * r) ? s.lt[r] : 0.0;
-            }
-        } else if (wave == NW - 1) {
-            if (b > 0) publish(b - 1);                   // nothing else: write-through stores stay off the working waves
-        } else {
-            const int fw = wave - 1, nfw = NW - 2;       // free waves
-            if (all_resident && b == 0 && nb > 1) {
-                // every remaining block column of S: they were written together with block column 0, so
-                // no polling (a straggler still reads as a sentinel -> retry path)
-                int ntot2 = 0;
-                for (int tc = 1; tc < nb; ++tc) ntot2 += nb - tc + 1;
-                for (int base = fw; base < ntot2; base += nfw * PB) {
-                    sf64x4 v2[PB];
-                    FrBlockSrc s2[PB];
-                    int i2[PB], t2[PB];
-#pragma unroll
-                    for (int j = 0; j < PB; ++j) {
-                        int u = base + nfw * j, tc = 1;
-                        const bool has = u < ntot2;
-                        u = has ? u : 0;
-                        while (u >= nb - tc + 1) { u -= nb - tc + 1; ++tc; }
-                        i2[j] = has ? tc + u : -1;
-                        t2[j] = tc;
-                        s2[j] = fr_block_src(fr, nb, tc + u, tc, lane);
-                    }
-                    {
-                        FrBlockRaw raw[PB];
-#pragma unroll
-                        for (int j = 0; j < PB; ++j)
-                            if (i2[j] >= 0) fr_block_issue(raw[j], s2[j]);
-                        fr_block_arrive(raw);
-#pragma unroll
-                        for (int j = 0; j < PB; ++j) {
-                            v2[j] = fr_block_value(raw[j]);
-                            if (i2[j] >= 0) stale |= fr_tag_stale(raw[j].t, fr.seqno);
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < PB; ++j)
-                        if (i2[j] >= 0)
-                            fr_block_put(fr_block_settle(s2[j], v2[j], spin_fail), colbuf(t2[j]), kp, nb, i2[j], lane);
-                }
-            }
-            // the blocks below the diagonal of THIS column: the one term that could not be applied earlier
-            if (fr.stamps && tid == 64 && b == 1) fr.stamps[56] = clock64();
-            if (b > 0)
-                for (int i = b + 1 + fw; i <= nb; i += nfw) {
-                    SvAcc a;
-                    sv_acc_load(a, cur, kp, i, c, g);
-                    sv_term_lds(a, colbuf(b - 1), kp, i, b, c, g);
-                    sv_acc_store(a, cur, kp, i, c, g);
-                }
-            if (fr.stamps && tid == 64 && b == 1) fr.stamps[57] = clock64();
-            if (b >= 1 && b + 1 < nb)
-                for (int i = b + 1 + fw; i <= nb; i += nfw) {
-                    SvAcc a;
-                    sv_acc_load(a, colbuf(b + 1), kp, i, c, g);
-                    sv_term_lds(a, colbuf(b - 1), kp, i, b + 1, c, g);
-                    sv_acc_store(a, colbuf(b + 1), kp, i, c, g);
-                }
-            if (fr.stamps && tid == 64 && b == 1) fr.stamps[58] = clock64();
-            const int tc = b + 2;
-            if (tc < nb)
-                for (int i = tc + fw; i <= nb; i += nfw) {
-                    if (!all_resident) {
-                        const FrBlockSrc s = fr_block_src(fr, nb, i, tc, lane);
-                        fr_block_wait(s, spin_fail);
-                        fr_block_put(fr_block_take(s, fr.seqno, spin_fail, stale), colbuf(tc), kp, nb, i, lane);
-                    }
-                    if (b >= 1) {
-                        SvAcc a;
-                        sv_acc_load(a, colbuf(tc), kp, i, c, g);
-                        int q = 0;
-                        for (; q < b && !(q + RS >= nb || b <= q + RS - 3); ++q) {}
-                        // read-back of this workgroup's own publication (the column has left the LDS ring): coherent
-                        // loads, every word checked against the sentinel like any other exchange read
-                        spin_fail |= sv_terms_glb<true>(a, xlop, xy, nb, i, tc, q, g, lane);
-                        for (; q < b; ++q) sv_term_lds(a, colbuf(q), kp, i, tc, c, g, (q & 1) != 0);
-                        sv_acc_store(a, colbuf(tc), kp, i, c, g);
-                    }
-                }
-        }
-        if (fr.stamps && tid == 64 && b == 1) fr.stamps[59] = clock64();
-        __syncthreads();
-        EKF_STAMP();
-        // panel: L_ib = S'_ib X^T for every row block below the diagonal (the residual row rides along)
-        for (int i = b + 1 + wave; i <= nb; i += NW) {
-            sv_panel_block(cur, dscr, kp, i, c, g);
-            if (fr.wdbg && i < nb) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    fr.lmat[(size_t)(EKF_RB * i + g + 4 * r) * fr.ldl + cb + c] = cur[(size_t)(EKF_RB * i + g + 4 * r) * SV_CLD + c];
-            }
-        }
-        __syncthreads();
-    }
-    EKF_STAMP();
-    if (wave == NW - 1) publish(nb - 1);
-    if ((bad | spin_fail | stale) && lane == 0) {
-        atomicOr(fr.status, (bad ? EKF_ST_NOT_SPD : 0) | (spin_fail ? EKF_ST_TIMEOUT : 0) | (stale ? EKF_ST_STALE_S : 0));
-        if (bad) {      // diagnostics: which waves saw it, and the first block column
+template <int NB>
+__device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, double* v_sm) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (fr.stamps && tid == 0) fr.stamps[62] = wall_clock64();
+    SvIoFused io{fr, 0, 0};
+    int bad = 0, badcol = 0;
+    sv_factor<NB>(fr, io, v_sm, bad, badcol);
+    if ((bad | io.spin_fail | io.stale) && lane == 0) {
+        atomicOr(fr.status, (bad ? EKF_ST_NOT_SPD : 0) | (io.spin_fail ? EKF_ST_TIMEOUT : 0) | (io.stale ? EKF_ST_STALE_S : 0));
+        if (bad) {      // diagnostics: which wave saw it, and the first block column
             atomicOr(fr.status + 1, 1 << wave);
-            atomicCAS(fr.status + 2, 0, badb);
+            atomicCAS(fr.status + 2, 0, badcol);
         }
     }
-    EKF_STAMP();
     if (fr.stamps && tid == 0) fr.stamps[63] = wall_clock64();
-#undef EKF_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -833,13 +643,13 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
 // One instantiation per number of 16-row blocks NB = kpad / 16: the forward substitution is unrolled
 // over NB, and a kernel that carried all twelve variants spilled registers.
 template <typename T, int NU, int MODEL, int NB>
-__global__ __launch_bounds__(FR_T) void ekf_front_kernel(EkfFrame fr, int RS) {
+__global__ __launch_bounds__(FR_T) void ekf_front_kernel(EkfFrame fr) {
     extern __shared__ __attribute__((aligned(16))) double fr_sm[];
     const int nb = fr.kpad / EKF_RB, nS = nb * (nb + 1) / 2;
     const int bx = blockIdx.x;
     if (bx == 0) fr_role_measure<MODEL>(fr, fr_sm);
     else if (bx <= nS) fr_role_sblock<T, MODEL>(fr, bx - 1, nS, fr_sm);
-    else if (bx == nS + 1) fr_role_factor(fr, RS, fr_sm);
+    else if (bx == nS + 1) fr_role_factor<NB>(fr, fr_sm);
     else fr_role_chunk<T, NU, MODEL, NB>(fr, bx - nS - 2, fr_sm);
 }
 
@@ -856,11 +666,10 @@ static void ekf_front_go(const EkfFrame& fr, hipStream_t s) {
     const int nb = fr.kpad / EKF_RB, nS = nb * (nb + 1) / 2;
     const size_t lds_s = ((size_t)fr.k * JC + NSLOT * 16 + 32 + fr.kpad) * 8 + 16;
     const size_t lds_c = ((size_t)fr.k * JC + (size_t)fr.kpad * FR_ALD) * 8 + 72 * 4 + 8 * 64 * 8 + 16;
-    const size_t lds_f = (size_t)ekf_solve_stream_lds_bytes(fr.kpad, fr.k);
+    const size_t lds_f = (size_t)sv_lds_doubles(NB) * 8;
     size_t lds = lds_s > lds_c ? lds_s : lds_c;
     if (lds_f > lds) lds = lds_f;
-    hipLaunchKernelGGL((ekf_front_kernel<T, NU, MODEL, NB>), dim3(nS + 2 + fr.ncols / 64), dim3(FR_T), lds, s, fr,
-                       ekf_solve_stream_ring(fr.kpad, fr.k));
+    hipLaunchKernelGGL((ekf_front_kernel<T, NU, MODEL, NB>), dim3(nS + 2 + fr.ncols / 64), dim3(FR_T), lds, s, fr);
 }
 
 template <typename T>

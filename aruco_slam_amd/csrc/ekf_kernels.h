@@ -30,9 +30,9 @@ struct EkfFrame {
     int32_t* lmcol;        // [mmax] first state column of each detection
     double* amat;          // A = H (P+Q), [kmax, lda] f64
     int64_t lda;
-    double* sblk;          // S = Hs (P+Q)[supp,supp] Hs^T + R in 16x16 blocks (lower block triangle),
-                           // [block column][sblk_rows][16]: what the solve kernel streams into LDS
-    int32_t sblk_rows;
+    double* sblk;          // S = Hs (P+Q)[supp,supp] Hs^T + R in 16x16 blocks (lower block triangle), block (i, tc) at
+                           // (i (i + 1) / 2 + tc) * 256 in OP memory order (ekf_solve_device.h); diagonal blocks symmetric
+    int32_t sblk_rows;     // (unused)
     double* lmat;          // Cholesky factor L of S, [kmax, ldl] f64 (lower)
     int32_t ldl;
     double* dinv;          // inverse of the 16x16 diagonal blocks of L, [kmax/16,16,16]
@@ -71,7 +71,7 @@ struct EkfFrame {
     double* xl_next;           // the other buffer, re-armed during this frame for the next fused frame
     int32_t xl_dop, xl_y, xl_jac;   // offsets (doubles) of the Dinv operands, y and the Jacobian rows inside xl
     int32_t xl_len;            // doubles per buffer
-    double* xs;                // = xl + offset: S blocks, layout of sblk
+    double* xs;                // = xl + offset: S blocks, layout of sblk (OP memory order)
     double* xr;                // = xl + offset: [kmax] z - h (0 for rows k..kpad-1)
     double* xs_tag;            // = xl + offset: frame tag of S block (row block i, block column tc) at [16 tc + i]
     int32_t n_lm;              // landmarks in the state (index validation; model 1 injection)
@@ -96,8 +96,6 @@ __device__ __forceinline__ int ekf_lm_column(const EkfFrame& fr, int lmd, int j,
 
 // fused gather + solve + panel (+ injection); see ekf_front_impl.h
 template <typename T> void ekf_launch_front(const EkfFrame& fr, hipStream_t s);
-int ekf_solve_stream_ring(int kpad, int k);
-int ekf_solve_stream_lds_bytes(int kpad, int k);
 template <typename T> void ekf_launch_gather(const EkfFrame& fr, hipStream_t s);
 void ekf_launch_solve(const EkfFrame& fr, hipStream_t s);
 template <typename T> void ekf_launch_panel(const EkfFrame& fr, hipStream_t s);

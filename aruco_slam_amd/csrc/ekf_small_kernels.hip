@@ -10,6 +10,7 @@
 // The reference forms K = P H^T S^-1 and P <- (I - K H) P.  With S = L L^T and
 // W = L^-1 H P (P symmetric) this is dx = W^T L^-1 (z-h) and P <- P - W^T W.
 #include "ekf_kernels.h"
+#include "ekf_solve_device.h"
 
 // --------------------------------------------------------------------------
 // gather
@@ -114,13 +115,13 @@ __global__ __launch_bounds__(256) void ekf_gather_kernel(EkfFrame fr) {
             us[e] = acc;
         }
         __syncthreads();
+        double v;
         {
             const int i = tid >> 4, c2 = tid & 15, r1 = 16 * bi + i, r2 = 16 * bj + c2;
-            double v;
             if (r1 >= k || r2 >= k) {
                 v = (r1 == r2) ? 1.0 : 0.0;            // identity padding
             } else if (r2 > r1) {
-                v = 0.0;                               // strict upper part of a diagonal block
+                v = 0.0;                               // strict upper part of a diagonal block: mirrored below
             } else {
                 const double* h1 = hs + r1 * JC;
                 const int s1 = EKF_CAM + LMD * (r1 / RD - j0);
@@ -131,8 +132,11 @@ __global__ __launch_bounds__(256) void ekf_gather_kernel(EkfFrame fr) {
                 for (int d = 0; d < LMD; ++d) acc = __builtin_fma(h1[EKF_CAM + d], us[(s1 + d) * 16 + c2], acc);
                 v = acc;
             }
-            fr.sblk[((size_t)bj * fr.sblk_rows + r1) * 16 + c2] = v;
         }
+        __syncthreads();                               // `us` is free: it becomes the block's tile
+        us[(tid >> 4) * 17 + (tid & 15)] = v;
+        __syncthreads();
+        if (tid < 64) sv_sblock_emit<false>(fr.sblk + sv_blk_index(bi, bj), us, bi == bj, tid);
         return;
     }
     double pc[EKF_CAM];
@@ -185,166 +189,36 @@ template void ekf_launch_gather<double>(const EkfFrame&, hipStream_t);
 // --------------------------------------------------------------------------
 #include "ekf_solve_device.h"
 
-// number of block columns resident in LDS: all of them when they fit (kpad <= 128), else a ring
-int ekf_solve_stream_ring(int kpad, int k) {
-    const size_t col = (size_t)(kpad + 1) * SV_CLD * sizeof(double);
-    const size_t fixed = (8 + 2 * 16 * 17) * sizeof(double);     // + X = L_bb^-1 scratch, two slots
-    (void)k;
-    int rs = (int)((160 * 1024 - fixed) / col);
-    const int nb = kpad / EKF_RB;
-    if (rs > nb) rs = nb;
-    return rs < 4 ? 4 : rs;
-}
-int ekf_solve_stream_lds_bytes(int kpad, int k) {
-    return (int)(((size_t)ekf_solve_stream_ring(kpad, k) * (kpad + 1) * SV_CLD + 8 + 2 * 16 * 17) * sizeof(double));
-}
-
-__global__ __launch_bounds__(SV_T) void ekf_solve_stream_kernel(EkfFrame fr, int RS) {
+// One workgroup: the shared register-resident factorisation (ekf_solve_device.h: sv_factor) with the
+// plain IO policy.  One instantiation per block count NB = kpad / 16.
+template <int NB>
+__global__ __launch_bounds__(SV_T) void ekf_solve_kernel(EkfFrame fr) {
     extern __shared__ __attribute__((aligned(16))) double v_sm[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
-    const int kp = fr.kpad, nb = kp / EKF_RB, rows = kp + 1;
-    // RS block columns live in LDS: all of them (RS == nb) or a ring (column c in slot c % RS,
-    // overwritten when column c + RS is built, i.e. during iteration c + RS - 2)
-    double* ring = v_sm;                                         // [RS][rows][SV_CLD]
-    double* dscr0 = v_sm + (size_t)RS * rows * SV_CLD + 8;       // [2][16][17] X = L_bb^-1 of block column b (slot b & 1)
-    const bool all_resident = RS >= nb;
-    auto colbuf = [&](int col) { return ring + (size_t)(col % RS) * rows * SV_CLD; };
-    constexpr int NW = SV_T / 64;
-    int nstamp = 0;
-#define EKF_STAMP() do { if (fr.stamps && tid == 0) fr.stamps[nstamp] = clock64(); ++nstamp; } while (0)
-    EKF_STAMP();
-    // prologue.  Block columns brought into LDS before the first pivot chain: all of them when
-    // they are all resident, else 0 and 1 (column c >= 2 then arrives during iteration c - 2).
-    // All loads of a wave's first PB blocks are issued together: one exposed memory round trip.
-    constexpr int PB = 6;
-    const int ncol0 = all_resident ? nb : (nb > 1 ? 2 : 1);
-    int ntot = 0;
-    for (int tc = 0; tc < ncol0; ++tc) ntot += nb - tc + 1;
-    sf64x4 pv[PB];
-    int pi[PB], ptc[PB];
-#pragma unroll
-    for (int j = 0; j < PB; ++j) {
-        int u = wave + NW * j, tc = 0;
-        const bool has = u < ntot;
-        u = has ? u : 0;
-        while (u >= nb - tc + 1) { u -= nb - tc + 1; ++tc; }
-        pi[j] = has ? tc + u : -1;
-        ptc[j] = tc;
-        pv[j] = sv_fetch_block(fr, kp, nb, has ? tc + u : 0, tc, lane);
-    }
-    EKF_STAMP();
-#pragma unroll
-    for (int j = 0; j < PB; ++j)
-        if (pi[j] >= 0) sv_put_block(pv[j], colbuf(ptc[j]), kp, nb, pi[j], lane);
-    for (int u0 = wave + NW * PB; u0 < ntot; u0 += NW) {      // (more than PB blocks per wave: rare)
-        int u = u0, tc = 0;
-        while (u >= nb - tc + 1) { u -= nb - tc + 1; ++tc; }
-        sv_put_block(sv_fetch_block(fr, kp, nb, tc + u, tc, lane), colbuf(tc), kp, nb, tc + u, lane);
-    }
-    __syncthreads();
-    EKF_STAMP();
-
-    // emission of a finished block column (from its LDS copy): -L blocks and Dinv in MFMA-operand
-    // order, y, the plain Dinv; one wave
-    auto emit = [&](int pb) {
-        const double* colb = colbuf(pb);
-        const double* dscr = dscr0 + (pb & 1) * (16 * 17);
-        for (int i = pb + 1; i < nb; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                fr.lop[sv_lop_index(i, pb) + r * 64 + lane] =
-                    -colb[(size_t)(EKF_RB * i + (lane & 15)) * SV_CLD + (lane >> 4) + 4 * r];
-        if (lane < EKF_RB) fr.yvec[EKF_RB * pb + lane] = colb[(size_t)kp * SV_CLD + lane];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            fr.dop[(size_t)(pb * 4 + r) * 64 + lane] = dscr[(lane & 15) * 17 + (lane >> 4) + 4 * r];
-            fr.dinv[(size_t)(EKF_RB * pb + g + 4 * r) * EKF_RB + c] = dscr[(g + 4 * r) * 17 + c];
-        }
-    };
-    int bad = 0;
-    for (int b = 0; b < nb; ++b) {
-        const int cb = EKF_RB * b;
-        double* cur = colbuf(b);
-        double* dscr = dscr0 + (b & 1) * (16 * 17);
-        if (wave == 0) {
-            // the diagonal block: last left-looking term, 16-pivot chain, X = L_bb^-1 into LDS
-            SvDiag s;
-            s.m = sv_diag_load(cur, b, c, g);
-            if (b > 0) s.m = sv_diag_term(s.m, colbuf(b - 1), b, c, g);
-            bad |= sv_diag_chain(s, c, g);
-            sv_x_store(s.x, dscr, c, g);
-            if (fr.wdbg) {                               // dense L for tests only
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    fr.lmat[(size_t)(cb + c) * fr.ldl + cb + g + 4 * r] = (c >= g + 4 * r) ? s.lt[r] : 0.0;
-            }
-        } else {
-            const int fw = wave - 1, nfw = NW - 1;       // free waves
-            // the blocks below the diagonal of THIS column: the one term that could not be applied earlier
-            if (b > 0)
-                for (int i = b + 1 + fw; i <= nb; i += nfw) {
-                    SvAcc a;
-                    sv_acc_load(a, cur, kp, i, c, g);
-                    sv_term_lds(a, colbuf(b - 1), kp, i, b, c, g);
-                    sv_acc_store(a, cur, kp, i, c, g);
-                }
-            if (b > 0 && wave == NW - 1) emit(b - 1);
-            // block column b+1: the q = b-1 term (operands still in LDS)
-            if (b >= 1 && b + 1 < nb)
-                for (int i = b + 1 + fw; i <= nb; i += nfw) {
-                    SvAcc a;
-                    sv_acc_load(a, colbuf(b + 1), kp, i, c, g);
-                    sv_term_lds(a, colbuf(b - 1), kp, i, b + 1, c, g);
-                    sv_acc_store(a, colbuf(b + 1), kp, i, c, g);
-                }
-            // block column b+2: fetched here unless it already is resident; then every finished term q <= b-1
-            // (from LDS while column q is still resident, else from the emitted -L blocks)
-            const int tc = b + 2;
-            if (tc < nb)
-                for (int i = tc + fw; i <= nb; i += nfw) {
-                    if (!all_resident)
-                        sv_put_block(sv_fetch_block(fr, kp, nb, i, tc, lane), colbuf(tc), kp, nb, i, lane);
-                    if (b >= 1) {
-                        SvAcc a;
-                        sv_acc_load(a, colbuf(tc), kp, i, c, g);
-                        int q = 0;
-                        for (; q < b && !(q + RS >= nb || b <= q + RS - 3); ++q) {}   // first resident q
-                        sv_terms_glb(a, fr.lop, fr.yvec, nb, i, tc, q, g, lane);
-                        for (; q < b; ++q) sv_term_lds(a, colbuf(q), kp, i, tc, c, g, (q & 1) != 0);
-                        sv_acc_store(a, colbuf(tc), kp, i, c, g);
-                    }
-                }
-        }
-        __syncthreads();
-        EKF_STAMP();
-        // panel: L_ib = S'_ib X^T for every row block below the diagonal (the residual row rides along)
-        for (int i = b + 1 + wave; i <= nb; i += NW) {
-            sv_panel_block(cur, dscr, kp, i, c, g);
-            if (fr.wdbg && i < nb) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    fr.lmat[(size_t)(EKF_RB * i + g + 4 * r) * fr.ldl + cb + c] = cur[(size_t)(EKF_RB * i + g + 4 * r) * SV_CLD + c];
-            }
-        }
-        __syncthreads();
-        EKF_STAMP();
-    }
-    if (wave == NW - 1) emit(nb - 1);
-    if (bad && lane == 0) atomicOr(fr.status, EKF_ST_NOT_SPD);
-    EKF_STAMP();
-#undef EKF_STAMP
+    SvIoPlain io{fr};
+    int bad = 0, badcol = 0;
+    sv_factor<NB>(fr, io, v_sm, bad, badcol);
+    if (bad && (threadIdx.x & 63) == 0) atomicOr(fr.status, EKF_ST_NOT_SPD);
 }
 
+template <int NB>
+static void ekf_solve_go(const EkfFrame& fr, hipStream_t s) {
+    hipLaunchKernelGGL(ekf_solve_kernel<NB>, dim3(1), dim3(SV_T), sv_lds_doubles(NB) * sizeof(double), s, fr);
+}
 void ekf_launch_solve(const EkfFrame& fr, hipStream_t s) {
-    static bool once = false;
-    if (!once) {   // > 64 KB of dynamic LDS needs the opt-in
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ekf_solve_stream_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        once = true;
+    switch (fr.kpad / EKF_RB) {
+        case 1: return ekf_solve_go<1>(fr, s);
+        case 2: return ekf_solve_go<2>(fr, s);
+        case 3: return ekf_solve_go<3>(fr, s);
+        case 4: return ekf_solve_go<4>(fr, s);
+        case 5: return ekf_solve_go<5>(fr, s);
+        case 6: return ekf_solve_go<6>(fr, s);
+        case 7: return ekf_solve_go<7>(fr, s);
+        case 8: return ekf_solve_go<8>(fr, s);
+        case 9: return ekf_solve_go<9>(fr, s);
+        case 10: return ekf_solve_go<10>(fr, s);
+        case 11: return ekf_solve_go<11>(fr, s);
+        default: return ekf_solve_go<12>(fr, s);
     }
-    hipLaunchKernelGGL(ekf_solve_stream_kernel, dim3(1), dim3(SV_T),
-                       ekf_solve_stream_lds_bytes(fr.kpad, fr.k), s, fr,
-                       ekf_solve_stream_ring(fr.kpad, fr.k));
 }
 
 // --------------------------------------------------------------------------

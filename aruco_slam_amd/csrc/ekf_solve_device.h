@@ -39,238 +39,417 @@ __device__ __forceinline__ double ekf_rsqrt_f64(double d) {
     return y;
 }
 
-// --------------------------------------------------------------------------
-// solve, column-streaming blocked Cholesky (kpad <= 192).  8 waves, one workgroup.
-//   * S block columns live in LDS: all of them (kpad <= 128) or a ring; a finished block column b is
-//     emitted in MFMA-operand order (-L, `lop`) -- the layout the panel kernel reads anyway -- and, in
-//     ring mode, is read back from there by the later left-looking updates;
-//   * per block column b:
-//       wave 0      : diagonal block (b,b): last left-looking term, then the 16-pivot chain as 16
-//                     rank-1 MFMA updates in registers (sv_diag_chain: no cross-lane traffic at all),
-//                     carrying I_16 along -> X = L_bb^-1 (= Dinv_b), handed to the others through LDS
-//       other waves : meanwhile the last left-looking term of the blocks below the diagonal, the
-//                     pre-updates of block columns b+1 and b+2, the emission of block column b-1
-//       barrier
-//       all waves   : panel  L_ib = S'_ib X^T  (4 MFMAs per 16x16 block; the residual rides along as
-//                     row kp: its factor row is y = L^-1 (z - h))
-//       barrier
-//   * S itself comes finished from the gather launch (`sblk`) / the S-block workgroups (fused kernel).
-// Round 1 ran the chain with lane = row on every row of the block column (v_readlane broadcasts,
-// 15 - j updates per pivot): ~310 cycles per pivot, ~5k cycles per block column.  The chain below is
-// latency-bound at ~150 cycles per pivot, and only the diagonal block is on it.
-// --------------------------------------------------------------------------
+// ============================================================================================
+// Blocked Cholesky of S (k <= 192) by ONE workgroup of 8 waves, everything in registers.
+// Shared by the stand-alone solve kernel (ekf_small_kernels.hip) and the factorisation role of the
+// fused front kernel (ekf_front_impl.h): same code, same bits; they differ only in the IO policy.
+//
+// OP layout of a 16 x 16 block B in one wave: lane l = 16 g + c holds B[c][g + 4 r] in register r
+// (r = 0..3).  It is at once
+//     * the A operand of v_mfma_f64_16x16x4 for the k-chunk r          (lane (i = c, k = g)),
+//     * the B operand of the same instruction for B^T                  (lane (k = g, j = c)),
+//     * the accumulator (C) layout of B^T                              (lane (col = c, row = g + 4 r)),
+// so a block that is kept as "OP layout of itself" can be multiplied, accumulated and handed to the
+// consumers (`lop` / `dop` ARE this layout) without a single cross-lane move or LDS transpose:
+//     panel   OP(L_ib)   = sum_r mfma(OP(X)[r], OP(S'_ib)[r])                 (L_ib = S'_ib X^T)
+//     update  OP(S'_itc) -= sum_r mfma(OP(L_tc,b)[r], OP(L_ib)[r])            (S'_itc -= L_ib L_tc,b^T)
+// In memory (exchange buffer / `sblk`): word (r >> 1) 128 + 2 l + (r & 1) of the block's 256 words:
+// two 16-byte accesses per lane, each instruction covers 1 KB of whole cache lines.
+//
+// Ownership: wave w keeps row blocks w and w + 8 (row block NB is the residual row: z - h rides
+// along, its factor row is y = L^-1 (z - h)) with all their blocks (i, tc), tc <= i, in registers.
+// Per block column b (ONE barrier; everything else is ordered by per-row flags in LDS):
+//   phase 1  owner of row b : chain on the finished diagonal block -> X = L_bb^-1 (OP layout = `dop`
+//                             order) into LDS, published;   everyone: the trailing updates of step
+//                             b - 1 that are not urgent (block columns >= b + 1)
+//   barrier
+//   phase 2  every row i > b: L_ib by 4 MFMAs, into LDS (the other rows need it as an operand; flag)
+//                             and published (`lop` order = the registers as they are)
+//   phase 3  every row i > b: the urgent updates, block columns b + 1 and b + 2 (so that the next chain
+//                             and the next panel start from finished blocks, and the SIMD partner of
+//                             the next chain has nothing left to do).  Row b + 1 -- the next chain --
+//                             needs nothing but its own block and goes straight on.
+// The chain itself (sv_chain): LDL^T by 16 rank-1 updates in the vector ALU, operands moved by DPP row
+// broadcasts and cross-row swaps only (see there).  The square roots are taken once at the end.
+// (Round 1: lane = row, v_readlane broadcasts, 15 - j updates per pivot: ~310 cycles per pivot on
+// every row of the block column, plus an LDS round trip per left-looking term: ~6k cycles per block
+// column at k = 96.)
+// ============================================================================================
 #define SV_T 512
-#define SV_CLD 18
+#define SV_NW (SV_T / 64)
 
 __device__ __forceinline__ size_t sv_lop_index(int i, int q) { return (size_t)(i * (i - 1) / 2 + q) * 256; }
+__device__ __forceinline__ size_t sv_blk_index(int i, int tc) { return (size_t)(i * (i + 1) / 2 + tc) * 256; }
+__host__ __device__ constexpr int sv_lds_doubles(int nb) { return 512 + (nb + 1) * 256 + 64; }     // X (two slots) | L_ib of every row | flags
 
-// ---------------------------------------------------------------------------
-// C layout of a 16 x 16 block in one wave (v_mfma_f64_16x16x4 accumulator): lane = 16 g + c,
-// register r <-> element [g + 4 r][c].
-// ---------------------------------------------------------------------------
-// value of lane J of each 16-lane row, in every lane of that row (DPP row_newbcast: stays in the VALU)
+typedef double sv_d2 __attribute__((ext_vector_type(2)));
+// 16-byte coherent load for the in-launch exchange: a volatile access through a global-address-space
+// pointer compiles to `global_load_dwordx4 ... sc0 sc1` (system scope, a superset of the agent scope
+// the 8-byte builtins give) and stays visible to the compiler -- unlike an inline-asm load, whose
+// destination registers the compiler may copy or spill before the hand-written wait (round 1 / the first
+// version of this file did that; tools/asm_load_hazards.py found real copies in flight).
+typedef const volatile sv_d2 __attribute__((address_space(1))) * sv_gld16_t;
+__device__ __forceinline__ sv_d2 ekf_ldc16(const double* p) { return *(sv_gld16_t)p; }
+
+// 1 / d for a wave-uniform d: v_rcp_f64 (about 2^-23) and one cubic step (error ~ e^3)
+__device__ __forceinline__ double sv_rcp(double d) {
+    const double r0 = __builtin_amdgcn_rcp(d);
+    const double e = __builtin_fma(-d, r0, 1.0);
+    const double p = __builtin_fma(e, e, e);
+    return __builtin_fma(r0, p, r0);
+}
+
+// value of lane J of each 16-lane row, in every lane of that row (one v_mov_b64_dpp row_newbcast)
 template <int J> __device__ __forceinline__ double sv_row_bcast(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x150 + J, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x150 + J, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
+    return __builtin_amdgcn_update_dpp(v, v, 0x150 + J, 0xf, 0xf, false);
+}
+// the values of 16-lane group G0, in all four groups (gfx950 cross-row swaps; semantics checked by
+// tools/probes/permlane_probe.hip:  permlane16_swap(D, S) -> D' = [D.r0 S.r0 D.r2 S.r2], S' = [D.r1 S.r1 D.r3 S.r3];
+// permlane32_swap(D, S) -> D' = [D.lo32 S.lo32], S' = [D.hi32 S.hi32])
+template <int G0> __device__ __forceinline__ int sv_group_bcast32(int v) {
+    auto p = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    const int x = (G0 & 1) ? p[1] : p[0];
+    auto q = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return (G0 & 2) ? q[1] : q[0];
+}
+template <int G0> __device__ __forceinline__ double sv_group_bcast(double v) {
+    return __hiloint2double(sv_group_bcast32<G0>(__double2hiint(v)), sv_group_bcast32<G0>(__double2loint(v)));
 }
 
-// Cholesky of a 16 x 16 SPD block M (bitwise symmetric, C layout) as 16 rank-1 updates:
-//   pivot j:  d = M[j][j];  y = 1/sqrt(d);  l_j = M[:, j] y;  M -= l_j l_j^T;
-//             x_j = T[j, :] y;  T -= l_j x_j      (T starts as I_16; the rows x_j are X = L^-1)
-// Row j of the symmetric M -- register j/4 in the 16 lanes of group g = j%4 -- IS column j, and a
-// vector that lives in ONE 16-lane group with zeros in the other three is a valid A operand
-// (lane (i, k)) and B operand (lane (k, j')) of v_mfma_f64_16x16x4 for the rank-1 product: no
-// cross-lane movement except the broadcast of d inside the group.  Entries of rows / columns that
-// are already eliminated turn into rounding residue; they only ever touch eliminated rows again.
-// Out: x (C layout: X[g + 4 r][c], exact zeros above the diagonal), lt (debug: lt[r] = L[c][g + 4 r],
-// meaningful for c >= g + 4 r).  Returns != 0 if a pivot was not positive.
-struct SvDiag { sf64x4 m, t, x, lt; };
-template <int J>
-__device__ __forceinline__ void sv_pivot(SvDiag& s, int g, int& bad) {
+// The 16-pivot chain: LDL^T of one 16 x 16 block by rank-1 updates, entirely in the vector ALU of one
+// wave (on MI355X an f64 MFMA costs as many cycles as the vector FMAs it replaces -- 64 cycles per
+// 16x16x4 -- so a rank-1 update through the matrix pipe would waste three quarters of it).
+// C layout: lane (c, g), register rr <-> M[g + 4 rr][c].  Pivot J (R = J / 4, G0 = J % 4):
+//     M[i][c] -= M[i][J] * M[J][c] / d_J
+//   * column J by row index, M[g + 4 rr][J], sits in lane (J, g): a row broadcast (DPP) of register rr;
+//   * row J by column index, M[J][c], sits in register R of group G0: a group broadcast (two swaps per dword);
+//   * U = (L'^-1)^T is carried along:  U[i][c] -= U[i][J] * L'[c][J]  needs the same two kinds of operand
+//     and no other; at the end U in C layout IS L'^-1 in OP layout, i.e. `dop` order: no transpose.
+// Only columns c > J are touched (exact zeros above the diagonal of L'^-1, row J of it stays intact).
+// the values of 16-lane group G0 in all four groups through the LDS crossbar (ds_bpermute: two instructions
+// to issue, ~80 cycles until the data is back -- time the chain spends on other instructions; the swap
+// version above costs the same ~75 cycles, but as ISSUE time)
+template <int G0> __device__ __forceinline__ double sv_group_bcast_async(double v, int c) {
+    const int addr = 4 * (16 * G0 + c);
+    return __hiloint2double(__builtin_amdgcn_ds_bpermute(addr, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(addr, __double2loint(v)));
+}
+
+// The 16-pivot chain: LDL^T of one 16 x 16 block by rank-1 updates, entirely in the vector ALU of one
+// wave (on MI355X an f64 MFMA costs as many cycles as the vector FMAs it replaces -- 64 cycles per
+// 16x16x4 -- so a rank-1 update through the matrix pipe would waste three quarters of it).
+// C layout: lane (c, g), register rr <-> M[g + 4 rr][c].  Pivot J (R = J / 4, G0 = J % 4):
+//     M[i][c] -= M[i][J] * M[J][c] / d_J          for c > J
+//   * column J by row index, M[g + 4 rr][J], sits in lane (J, g): a row broadcast of register rr, folded
+//     into the FMA (v_fmac_f64 with a DPP source, row_newbcast);
+//   * row J by column index, M[J][c], sits in register R of group G0 and is needed in all four groups: a
+//     cross-group broadcast.  It is taken ONE PIVOT AHEAD (row J + 1 before update J, corrected by one FMA
+//     with the scalar M[J+1][J]), so its latency overlaps the FMAs of pivot J;
+//   * U = (L'^-1)^T is carried along:  U[i][c] -= U[i][J] * L'[c][J]  needs the same two kinds of operand
+//     and no other; at the end U in C layout IS L'^-1 in OP layout, i.e. `dop` order: no transpose.
+// Only columns c > J are touched (exact zeros above the diagonal of L'^-1, row J of it stays intact).
+// Measured (tools/probes/chain_probe.hip, one wave): see DESIGN.md section 9.
+struct SvChain {
+    sf64x4 m;        // the block (C layout) on entry; destroyed
+    sf64x4 lp;       // debug: OP layout of L' (unit lower)
+    sf64x4 dr;       // debug: pivots by g + 4 rr
+    double dcol;     // pivot d_c in every lane with lane & 15 == c
+    int bad;
+};
+template <int J, bool DBG>
+__device__ __forceinline__ void sv_pivot(SvChain& s, sf64x4& u, double& rowv, int c, int g) {
     constexpr int R = J >> 2, G0 = J & 3;
-    const double d = sv_row_bcast<J>(s.m[R]);
-    const bool mine = (g == G0);
-    bad |= (mine && !(d > 0.0)) ? 1 : 0;
-    const double y = ekf_rsqrt_f64(d);
-    const double ym = mine ? y : 0.0;
-    const double op = s.m[R] * ym;                 // L[c][J]        (group G0)
-    const double xo = s.t[R] * ym;                 // X[J][c]        (group G0)
-    s.x[R] = mine ? xo : s.x[R];
-    s.lt[R] = mine ? op : s.lt[R];
-    const double nop = -op;
-    s.m = __builtin_amdgcn_mfma_f64_16x16x4f64(nop, op, s.m, 0, 0, 0);
-    s.t = __builtin_amdgcn_mfma_f64_16x16x4f64(nop, xo, s.t, 0, 0, 0);
+    constexpr int J1 = (J + 1) & 15, R1 = J1 >> 2, G1 = J1 & 3;
+    double nxt = 0.0, a1 = 0.0;
+    if (J < 15) {                                                    // row J + 1 as it is BEFORE update J
+        nxt = sv_group_bcast_async<G1>(s.m[R1], c);
+        a1 = ekf_readlane_f64(s.m[R1], 16 * G1 + J);                 // M[J + 1][J]
+    }
+    const double d = ekf_readlane_f64(rowv, J);                      // M[J][J]
+    s.bad |= !(d > 0.0);
+    const double r = sv_rcp(d);
+    s.dcol = (c == J) ? d : s.dcol;
+    const double lc = rowv * r;                                      // L'[c][J] (c >= J; 1 on the diagonal)
+    const double nl = (c > J) ? -lc : 0.0;                           // strictly below the pivot: row / column J themselves stay
+    if (DBG) {
+        s.lp[R] = (g == G0) ? lc : s.lp[R];
+        s.dr[R] = (g == G0) ? d : s.dr[R];
+    }
+    if (J == 15) return;
+    // x += row_bcast<J>(x) * nl in ONE instruction each (v_fmac_f64 takes a DPP source; hipcc emits a copy, a
+    // v_mov_b64_dpp and a v_fma_f64 instead).  s_nop: the data hazards of DPP reads (a VGPR written by the
+    // vector ALU needs two wait states before a DPP instruction reads it) are not tracked across inline asm.
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f64_dpp %0, %0, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %1, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %2, %2, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %3, %3, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %4, %4, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %5, %5, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %6, %6, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %7, %7, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(s.m[0]), "+v"(s.m[1]), "+v"(s.m[2]), "+v"(s.m[3]), "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3])
+                 : "v"(nl), "n"(J));
+    rowv = __builtin_fma(a1, nl, nxt);                               // M[J + 1][c] after update J (c > J)
 }
-__device__ __forceinline__ int sv_diag_chain(SvDiag& s, int c, int g) {
-    int bad = 0;
+// In: s.m.  Out: xop = OP layout of X = L^-1 (`dop` order), s.dcol (and s.lp, s.dr with DBG); returns != 0
+// if a pivot was not positive.
+template <bool DBG>
+__device__ __forceinline__ int sv_chain_t(SvChain& s, sf64x4& xop, int c, int g) {
+    s.bad = 0;
+    s.dcol = 1.0;
+    sf64x4 u;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        s.t[r] = (g + 4 * r == c) ? 1.0 : 0.0;
-        s.x[r] = 0.0;
-        s.lt[r] = 0.0;
+        u[r] = (g + 4 * r == c) ? 1.0 : 0.0;
+        s.lp[r] = 0.0;
+        s.dr[r] = 1.0;
     }
-    sv_pivot<0>(s, g, bad);  sv_pivot<1>(s, g, bad);  sv_pivot<2>(s, g, bad);  sv_pivot<3>(s, g, bad);
-    sv_pivot<4>(s, g, bad);  sv_pivot<5>(s, g, bad);  sv_pivot<6>(s, g, bad);  sv_pivot<7>(s, g, bad);
-    sv_pivot<8>(s, g, bad);  sv_pivot<9>(s, g, bad);  sv_pivot<10>(s, g, bad); sv_pivot<11>(s, g, bad);
-    sv_pivot<12>(s, g, bad); sv_pivot<13>(s, g, bad); sv_pivot<14>(s, g, bad); sv_pivot<15>(s, g, bad);
-    return __any(bad);
+    double rowv = sv_group_bcast<0>(s.m[0]);                         // row 0
+    sv_pivot<0, DBG>(s, u, rowv, c, g);   sv_pivot<1, DBG>(s, u, rowv, c, g);   sv_pivot<2, DBG>(s, u, rowv, c, g);
+    sv_pivot<3, DBG>(s, u, rowv, c, g);   sv_pivot<4, DBG>(s, u, rowv, c, g);   sv_pivot<5, DBG>(s, u, rowv, c, g);
+    sv_pivot<6, DBG>(s, u, rowv, c, g);   sv_pivot<7, DBG>(s, u, rowv, c, g);   sv_pivot<8, DBG>(s, u, rowv, c, g);
+    sv_pivot<9, DBG>(s, u, rowv, c, g);   sv_pivot<10, DBG>(s, u, rowv, c, g);  sv_pivot<11, DBG>(s, u, rowv, c, g);
+    sv_pivot<12, DBG>(s, u, rowv, c, g);  sv_pivot<13, DBG>(s, u, rowv, c, g);  sv_pivot<14, DBG>(s, u, rowv, c, g);
+    sv_pivot<15, DBG>(s, u, rowv, c, g);
+    // X = D^-1/2 L'^-1: row c of the OP layout is scaled by 1 / sqrt(d_c)
+    const double rs = ekf_rsqrt_f64(s.dcol);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) xop[rr] = u[rr] * rs;
+    return __any(s.bad);
 }
-// diagonal block (tc, tc) of a column buffer as a FULL symmetric matrix in C layout (the buffer's
-// lower triangle is authoritative: the S producer leaves zeros above the diagonal)
-__device__ __forceinline__ sf64x4 sv_diag_load(const double* buf, int tc, int c, int g) {
-    sf64x4 v;
+__device__ __forceinline__ int sv_chain(SvChain& s, sf64x4& xop, int c, int g, bool dbg) {
+    return dbg ? sv_chain_t<true>(s, xop, c, g) : sv_chain_t<false>(s, xop, c, g);
+}
+
+// One S block from its LDS tile (row-major [16][17]; on a diagonal block the lower triangle is
+// authoritative and is mirrored, so that the block arrives bitwise symmetric) into OP memory order.
+// One wave; every store instruction covers 1 KB of whole cache lines.  COH: write-through (sc1) stores
+// for the in-launch exchange of the fused front kernel.
+template <bool COH>
+__device__ __forceinline__ void sv_sblock_emit(double* dst, const double* tile, bool diag, int lane) {
+    const int c = lane & 15, g = lane >> 4;
+    double v[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int row = g + 4 * r;
-        v[r] = buf[(size_t)(EKF_RB * tc + max(row, c)) * SV_CLD + min(row, c)];
+        const int col = g + 4 * r;
+        v[r] = (diag && col > c) ? tile[col * 17 + c] : tile[c * 17 + col];
     }
-    return v;
+    const sv_d2 a = {v[0], v[1]}, b = {v[2], v[3]};
+    double* p0 = dst + 2 * lane;
+    double* p1 = dst + 128 + 2 * lane;
+    if (COH) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p0), "v"(a) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p1), "v"(b) : "memory");
+    } else {
+        *reinterpret_cast<sv_d2*>(p0) = a;
+        *reinterpret_cast<sv_d2*>(p1) = b;
+    }
 }
-// the q term of the diagonal block (tc, tc): M -= L_tq L_tq^T, operands from column buffer q
-__device__ __forceinline__ sf64x4 sv_diag_term(sf64x4 m, const double* qbuf, int tc, int c, int g) {
-    const double* br = qbuf + (size_t)(EKF_RB * tc + c) * SV_CLD + g;
-    double bv[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bv[r] = br[4 * r];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) m = __builtin_amdgcn_mfma_f64_16x16x4f64(-bv[r], bv[r], m, 0, 0, 0);
-    return m;
+
+// block operand from / to LDS (word r 64 + lane: conflict-free)
+__device__ __forceinline__ sf64x4 sv_lds_get(const double* p, int lane) {
+    return sf64x4{p[lane], p[64 + lane], p[128 + lane], p[192 + lane]};
 }
-// X (C layout) -> LDS scratch [16][17], row-major X[j][k]
-__device__ __forceinline__ void sv_x_store(const sf64x4& x, double* dscr, int c, int g) {
+__device__ __forceinline__ void sv_lds_put(double* p, const sf64x4& v, int lane) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dscr[(g + 4 * r) * 17 + c] = x[r];
+    for (int r = 0; r < 4; ++r) p[r * 64 + lane] = v[r];
 }
-// panel: row block i (> tc) of block column tc in `cur` becomes L_i,tc = S'_i,tc X^T, in place
-// (k order of the product: g + 4 r, the `dop` operand order).  Row block nb is the residual row.
-__device__ __forceinline__ void sv_panel_block(double* cur, const double* dscr, int kp, int i, int c, int g) {
-    const double* ar = cur + (size_t)min(EKF_RB * i + c, kp) * SV_CLD + g;      // residual block: rows alias kp
-    const double* br = dscr + c * 17 + g;
-    double av[4], bv[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { av[r] = ar[4 * r]; bv[r] = br[4 * r]; }
+__device__ __forceinline__ sf64x4 sv_mm(const sf64x4& a, const sf64x4& b) {          // OP(a) x OP(b)^T ...
     sf64x4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[r], bv[r], acc, 0, 0, 0);
+    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], b[r], acc, 0, 0, 0);
+    return acc;
+}
+__device__ __forceinline__ void sv_mm_sub(sf64x4& acc, const sf64x4& a, const sf64x4& b) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = EKF_RB * i + g + 4 * r;
-        if (row <= kp) cur[(size_t)row * SV_CLD + c] = acc[r];
-    }
+    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[r], b[r], acc, 0, 0, 0);
 }
 
-// C-in / C-out of row block i of the column buffer `tgt` (block column tc), one wave
-struct SvAcc { sf64x4 t, t2; };
-__device__ __forceinline__ void sv_acc_load(SvAcc& a, const double* tgt, int kp, int i, int c, int g) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        a.t[r] = tgt[min(EKF_RB * i + g + 4 * r, kp) * SV_CLD + c];
-        a.t2[r] = 0.0;
+// IO policy of the stand-alone solve kernel: S blocks and the residual from the gather launch
+// (plain loads), the factor to lop / dop / yvec / dinv (plain stores).  The fused front kernel has
+// its own policy (exchange buffer, sentinels, tags) in ekf_front_impl.h.
+struct SvIoPlain {
+    const EkfFrame& fr;
+    __device__ __forceinline__ sf64x4 load_block(int i, int tc, int lane) const {
+        const double* base = fr.sblk + sv_blk_index(i, tc);
+        const sv_d2 a = *reinterpret_cast<const sv_d2*>(base + 2 * lane);
+        const sv_d2 b = *reinterpret_cast<const sv_d2*>(base + 128 + 2 * lane);
+        return sf64x4{a[0], a[1], b[0], b[1]};
     }
-}
-__device__ __forceinline__ void sv_acc_store(const SvAcc& a, double* tgt, int kp, int i, int c, int g) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = EKF_RB * i + g + 4 * r;
-        if (row <= kp) tgt[row * SV_CLD + c] = a.t[r] + a.t2[r];
-    }
-}
-// one q term, operands from the LDS buffer of block column q:  -= L_iq L_tq^T
-__device__ __forceinline__ void sv_term_lds(SvAcc& a, const double* qbuf, int kp, int i, int tc, int c, int g,
-                                            bool second = false) {
-    const double* ar = qbuf + (size_t)min(EKF_RB * i + c, kp) * SV_CLD + g;   // residual block: rows alias kp
-    const double* br = qbuf + (size_t)(EKF_RB * tc + c) * SV_CLD + g;
-    double av[4], bv[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { av[r] = ar[4 * r]; bv[r] = br[4 * r]; }
-    if (second) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) a.t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[r], bv[r], a.t2, 0, 0, 0);
-    } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) a.t = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[r], bv[r], a.t, 0, 0, 0);
-    }
-}
-// q in [0, q1), operands from global: lop (-L blocks) and, for the residual block, y.
-// COH (fused front kernel, ring mode): the operands are this workgroup's own publication in the
-// exchange buffer, read back with coherent loads; every word is checked against the sentinel and
-// fetched again until it has landed (returns 1 if a bounded wait ran out).
-template <bool COH = false>
-__device__ __forceinline__ int sv_terms_glb(SvAcc& a, const double* __restrict__ lop,
-                                            const double* __restrict__ yv, int nb, int i, int tc, int q1,
-                                            int g, int lane) {
-    if (q1 <= 0) return 0;
-    int fail = 0;
-    // operands of term q+1 are in flight while the MFMAs of term q run
-    double av[4], bv[4], an[4], bn[4];
-    auto fetch = [&](int q, double (&x)[4], double (&y)[4]) {
+    __device__ __forceinline__ sf64x4 load_resid(int tc, int g) const {
+        sf64x4 v;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            x[r] = (i < nb) ? ekf_ldx<COH>(lop + sv_lop_index(i, q) + r * 64 + lane)
-                            : -ekf_ldx<COH>(yv + EKF_RB * q + g + 4 * r);
-            y[r] = -ekf_ldx<COH>(lop + sv_lop_index(tc, q) + r * 64 + lane);
+            const int row = EKF_RB * tc + g + 4 * r;
+            const double rv = fr.resid[min(row, fr.k - 1)];
+            v[r] = (row < fr.k) ? rv : 0.0;
         }
-    };
-    auto settle = [&](int q, double (&x)[4], double (&y)[4]) {
-        if (!COH) return;
+        return v;
+    }
+    // every block (i, tc), tc <= min(i, NB - 1), of the wave's rows i0 / i1 (row NB: the residual,
+    // replicated in all 16 rows of its "block" so that it rides through the same instructions)
+    template <int NB, int N0, int N1>
+    __device__ __forceinline__ void load_all(sf64x4 (&z0)[N0], sf64x4 (&z1)[N1], int i0, int i1, bool has0, bool has1,
+                                             int lane, int g) {
+#pragma unroll
+        for (int tc = 0; tc < N0; ++tc)
+            if (has0 && tc <= min(i0, NB - 1)) z0[tc] = (i0 == NB) ? load_resid(tc, g) : load_block(i0, tc, lane);
+#pragma unroll
+        for (int tc = 0; tc < N1; ++tc)
+            if (has1 && tc <= min(i1, NB - 1)) z1[tc] = (i1 == NB) ? load_resid(tc, g) : load_block(i1, tc, lane);
+    }
+    __device__ __forceinline__ void put_dinv(int b, const sf64x4& xop, int lane) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            fr.dop[(size_t)(b * 4 + r) * 64 + lane] = xop[r];
+            fr.dinv[(size_t)(EKF_RB * b + (lane & 15)) * EKF_RB + (lane >> 4) + 4 * r] = xop[r];
+        }
+    }
+    __device__ __forceinline__ void put_l(int i, int b, const sf64x4& y, int lane) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fr.lop[sv_lop_index(i, b) + r * 64 + lane] = -y[r];
+    }
+    __device__ __forceinline__ void put_y(int b, double yv, int c, bool active) {
+        if (active) fr.yvec[EKF_RB * b + c] = yv;
+    }
+};
+
+// The factorisation.  `lds`: sv_lds_doubles(NB) doubles.  Every wave of the workgroup calls it.
+template <int NB, class IO>
+__device__ __forceinline__ void sv_factor(const EkfFrame& fr, IO& io, double* lds, int& bad, int& badcol) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+    constexpr int N0 = NB < 8 ? NB : 8;             // blocks a row i <= 7 can have
+    constexpr bool TWO = NB >= 8;                   // rows 8 .. NB exist: second row per wave
+    constexpr int N1 = TWO ? NB : 1;
+    double* xbuf0 = lds;                            // [2][256]       OP(X) of block column b in slot b & 1
+    double* ybuf = lds + 512;                       // [NB + 1][256]  OP(L_ib) of the current block column
+    // yflag[i] = b + 1 once row i's L_ib of block column b is in ybuf (the rows publish at slightly different
+    // times; a hardware barrier there would make the next chain wait for the slowest panel)
+    volatile int* yflag = reinterpret_cast<volatile int*>(lds + 512 + (NB + 1) * 256);
+    if (tid <= NB) yflag[tid] = 0;
+    __syncthreads();
+    auto wait_row = [&](int row, int b) {           // row's block of column b is in ybuf
         int it = 0;
-        for (;;) {
-            bool pend = false;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pend = pend || ekf_is_sent(x[r]) || ekf_is_sent(-x[r]) || ekf_is_sent(y[r]) || ekf_is_sent(-y[r]);
-            if (!__any(pend)) break;
-            if (++it > EKF_SPIN_MAX) { fail = 1; break; }
-            __builtin_amdgcn_s_sleep(4);
-            fetch(q, x, y);
+        while (yflag[row] < b + 1) {
+            if (++it > (1 << 22)) break;            // (cannot happen: the publisher never waits for this wave)
+            __builtin_amdgcn_s_sleep(1);
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
-    fetch(0, av, bv);
-    for (int q = 0; q < q1; ++q) {
-        const int qn = min(q + 1, q1 - 1);
-        fetch(qn, an, bn);
-        settle(q, av, bv);
-        if (q & 1) {
+    auto post_row = [&](int row, int b) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) yflag[row] = b + 1;
+    };
+    // Row blocks 2 s and 2 s + 1 live on the two waves of SIMD s (waves w and w + 4 of a workgroup share a
+    // SIMD, and an f64 MFMA issued by one of them stalls the other's f64 vector instructions: a partner busy
+    // with trailing updates slowed the chain 2.5x, tools/probes/simd_share_probe.hip).  With this pairing
+    // the partner of the wave that runs chain b is either finished (b odd: row b - 1) or has nothing left to
+    // do (b even: row b + 1, whose blocks are all covered by the urgent updates below).
+    const int i0 = 2 * (wave & 3) + (wave >> 2), i1 = i0 + 8;
+    const bool has0 = i0 <= NB, has1 = TWO && i1 <= NB;
+    sf64x4 z0[N0], z1[N1];
+    // optional time stamps (debug): [0] start, [1] blocks in registers, [2 + 2 b] chain phase of block column b
+    // over (barrier), [3 + 2 b] panel + urgent update over; [47 + 2 b], [48 + 2 b] the chain alone (b < 4)
+    long long* stp = (fr.stamps && lane == 0) ? fr.stamps : nullptr;
+    if (stp && wave == 0) stp[0] = clock64();
+    io.template load_all<NB, N0, N1>(z0, z1, i0, i1, has0, has1, lane, g);
+    if (stp && wave == 0) stp[1] = clock64();
+    sf64x4 y0 = {0.0, 0.0, 0.0, 0.0}, y1 = {0.0, 0.0, 0.0, 0.0};      // OP(L_ib) of the wave's rows, column b
 #pragma unroll
-            for (int r = 0; r < 4; ++r) a.t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[r], bv[r], a.t2, 0, 0, 0);
-        } else {
+    for (int b = 0; b < NB; ++b) {
+        const int owner = ((b & 7) >> 1) + 4 * (b & 1);
+        // ---- phase 1
+        if (wave == owner) {
+            SvChain s;
+            s.m = (b < 8) ? z0[b < N0 ? b : 0] : z1[b < N1 ? b : 0];
+            sf64x4 xop;
+            if (stp && b < 4) stp[47 + 2 * b] = clock64();
+            const int badnow = sv_chain(s, xop, c, g, fr.wdbg != nullptr);
+            if (stp && b < 4) stp[48 + 2 * b] = clock64();
+            if (badnow && !bad) badcol = 100 + b;
+            bad |= badnow;
+            sv_lds_put(xbuf0 + (b & 1) * 256, xop, lane);
+            io.put_dinv(b, xop, lane);
+            if (fr.wdbg) {                            // dense L for tests only: L_bb = L' D^1/2
 #pragma unroll
-            for (int r = 0; r < 4; ++r) a.t = __builtin_amdgcn_mfma_f64_16x16x4f64(av[r], bv[r], a.t, 0, 0, 0);
+                for (int r = 0; r < 4; ++r) {
+                    const int col = g + 4 * r;
+                    const double sq = s.dr[r] * ekf_rsqrt_f64(s.dr[r]);
+                    fr.lmat[(size_t)(EKF_RB * b + c) * fr.ldl + EKF_RB * b + col] = (c >= col) ? s.lp[r] * sq : 0.0;
+                }
+            }
         }
+        if (b >= 1) {
+            // the trailing updates of step b - 1 that were not urgent: block columns b + 2 .. of the wave's rows
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { av[r] = an[r]; bv[r] = bn[r]; }
-    }
-    return fail;
-}
-
-// S entries of row block i of block column tc (rows 16i.., columns 16tc..): one wave, lane =
-// (row rr = lane & 15, column group cg = lane >> 4 -> 4 columns)
-// One 16x16 block (row block i, block column tc) of S as the gather launch left it in `sblk`
-// ([block column][row][16], 2 KB contiguous per block): lane = (row rr = lane >> 2, 4 columns).
-// Row block nb is the residual row: z - h of the block column's 16 rows.
-__device__ __forceinline__ sf64x4 sv_fetch_block(const EkfFrame& fr, int kp, int nb, int i, int tc, int lane) {
-    const int rr = lane >> 2, cg = lane & 3;
-    sf64x4 v;
-    if (i < nb) {
-        const double* src = fr.sblk + ((size_t)tc * fr.sblk_rows + EKF_RB * i + rr) * 16 + 4 * cg;
+            for (int tc = b + 2; tc < N0; ++tc)
+                if (has0 && tc <= min(i0, NB - 1)) {
+                    wait_row(tc, b - 1);
+                    sv_mm_sub(z0[tc], sv_lds_get(ybuf + tc * 256, lane), y0);
+                }
 #pragma unroll
-        for (int x = 0; x < 4; ++x) v[x] = src[x];
-    } else {
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const int r2 = EKF_RB * tc + 4 * cg + x;
-            const double rv = fr.resid[min(r2, fr.k - 1)];
-            v[x] = (r2 < fr.k) ? rv : 0.0;
+            for (int tc = b + 2; tc < N1; ++tc)
+                if (has1 && tc <= min(i1, NB - 1)) {
+                    wait_row(tc, b - 1);
+                    sv_mm_sub(z1[tc], sv_lds_get(ybuf + tc * 256, lane), y1);
+                }
         }
-    }
-    return v;
-}
-__device__ __forceinline__ void sv_put_block(const sf64x4& v, double* tgt, int kp, int nb, int i, int lane) {
-    const int rr = lane >> 2, cg = lane & 3;
-    if (i == nb && rr != 0) return;
-    const int row = (i < nb) ? EKF_RB * i + rr : kp;
+        __syncthreads();
+        if (stp && wave == 0) stp[2 + 2 * b] = clock64();
+        // ---- phase 2: panel
+        {
+            const sf64x4 xop = sv_lds_get(xbuf0 + (b & 1) * 256, lane);
+            if (has0 && i0 > b) {
+                y0 = sv_mm(xop, z0[b < N0 ? b : 0]);
+                sv_lds_put(ybuf + i0 * 256, y0, lane);
+                post_row(i0, b);
+            }
+            if (has1 && i1 > b) {
+                y1 = sv_mm(xop, z1[b < N1 ? b : 0]);
+                sv_lds_put(ybuf + i1 * 256, y1, lane);
+                post_row(i1, b);
+            }
+        }
+        // publication / emission: -L blocks in `lop` order (the registers as they are), y of the residual row
+        if (has0 && i0 > b) {
+            if (i0 < NB) io.put_l(i0, b, y0, lane);
+            else io.put_y(b, (c >> 2) == 0 ? y0[0] : (c >> 2) == 1 ? y0[1] : (c >> 2) == 2 ? y0[2] : y0[3], c, g == (c & 3));
+        }
+        if (has1 && i1 > b) {
+            if (i1 < NB) io.put_l(i1, b, y1, lane);
+            else io.put_y(b, (c >> 2) == 0 ? y1[0] : (c >> 2) == 1 ? y1[1] : (c >> 2) == 2 ? y1[2] : y1[3], c, g == (c & 3));
+        }
+        if (fr.wdbg) {
 #pragma unroll
-    for (int x = 0; x < 4; ++x) tgt[row * SV_CLD + 4 * cg + x] = v[x];
+            for (int r = 0; r < 4; ++r) {
+                if (has0 && i0 > b && i0 < NB) fr.lmat[(size_t)(EKF_RB * i0 + c) * fr.ldl + EKF_RB * b + g + 4 * r] = y0[r];
+                if (has1 && i1 > b && i1 < NB) fr.lmat[(size_t)(EKF_RB * i1 + c) * fr.ldl + EKF_RB * b + g + 4 * r] = y1[r];
+            }
+        }
+        // ---- phase 3: the urgent updates, block columns b + 1 and b + 2 (the rest waits for the next chain to
+        // run beside it).  Row b + 1 -- the next chain -- needs only its own L_(b+1)b and goes straight on; the
+        // other rows wait for the one or two blocks they need, not for every panel.
+#pragma unroll
+        for (int du = 1; du <= 2; ++du) {
+            const int tc = b + du;
+            if (tc < NB) {
+                if (has0 && i0 > b && tc < N0 && tc <= min(i0, NB - 1)) {
+                    if (i0 == tc) sv_mm_sub(z0[tc < N0 ? tc : 0], y0, y0);
+                    else {
+                        wait_row(tc, b);
+                        sv_mm_sub(z0[tc < N0 ? tc : 0], sv_lds_get(ybuf + tc * 256, lane), y0);
+                    }
+                }
+                if (has1 && i1 > b && tc <= min(i1, NB - 1)) {
+                    if (i1 == tc) sv_mm_sub(z1[tc < N1 ? tc : 0], y1, y1);
+                    else {
+                        wait_row(tc, b);
+                        sv_mm_sub(z1[tc < N1 ? tc : 0], sv_lds_get(ybuf + tc * 256, lane), y1);
+                    }
+                }
+            }
+        }
+        if (stp && wave == 0) stp[3 + 2 * b] = clock64();
+    }
 }
-

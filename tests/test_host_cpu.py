@@ -254,5 +254,6 @@ def test_hand_issued_loads_are_not_touched_before_their_wait(tmp_path):
         outs = list(pool.map(compile_one, srcs))
     for out in outs:
         n_loads, hazards = asm_load_hazards.scan(str(out))
-        assert n_loads >= 700, (out.name, n_loads)
+        if "cov_update" in out.name:
+            assert n_loads >= 1000, (out.name, n_loads)      # the f32 covariance update's operand ring
         assert not hazards, (out.name, hazards[:3])

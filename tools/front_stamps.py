@@ -15,11 +15,11 @@ us=lambda i:(st[i]-t0)/100.0
 print("fused front kernel timeline, us since the earliest stamp (100 MHz wall clock)")
 print("S-block wg0 start",us(60),"  measure wg published",us(55),"  S-block wg nS-1 stored",us(61))
 print("factor: start",us(62)," end",us(63))
-d=np.diff(st[:4+2*nb])
-print("  phases in shader cycles: issue",d[0]," S into LDS",d[1])
-for b in range(nb): print("  col",b," panel of the previous column + barrier",d[2+2*b]," chain phase (wave 0: diagonal block; others: terms) + barrier",d[3+2*b])
-for b in range(4): print("  col",b," wave 0: load + last term",st[47+2*b]-st[3+2*b]," 16-pivot chain alone",st[48+2*b]-st[47+2*b]," until the barrier opens",st[4+2*b]-st[48+2*b])
-print("  col 1, free wave 1 (cycles): since loop start",st[56]-st[5]," rest of column 1",st[57]-st[56]," column 2 term",st[58]-st[57]," column 3 terms",st[59]-st[58]," -> barrier opens",st[6]-st[59])
+print("  cycles: blocks into registers",st[1]-st[0])
+for b in range(nb):
+    prev = st[1] if b == 0 else st[3+2*(b-1)]
+    print("  col",b," chain phase + barrier",st[2+2*b]-prev," panel + barrier + urgent update",st[3+2*b]-st[2+2*b],
+          ("  (chain alone %d)" % (st[48+2*b]-st[47+2*b])) if b < 4 else "")
 print("chunk0: start",us(32)," A in LDS",us(33))
 for q in range(nb): print("  step",q,"done",us(34+q))
 print("  W/dx stored",us(34+nb))
