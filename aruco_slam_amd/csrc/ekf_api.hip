@@ -43,7 +43,8 @@ struct Layout {
     size_t elem;      // sizeof(cov element)
     size_t off_jac, off_resid, off_y, off_lmcol, off_amat, off_sblk, off_lmat, off_dinv, off_lop, off_dop, off_wpanel, off_wpanel2, off_prow, off_wdbg,
         off_idx, off_z, off_status, off_stamps, off_dx, off_diag, off_xyz, off_unc,
-        off_xl, off_done, total;
+        off_xl, off_done, off_sync, off_wsup, total;
+    int wsup_ld;      // row length of the compact support-column copy of W (pipelined sequence mode)
     // fused front kernel: one exchange buffer per fused-frame parity (offsets / length in doubles)
     size_t xl_len, xl_dop, xl_y, xl_jac, xl_tag, xl_xs, xl_xr, xl_stag;
 };
@@ -94,6 +95,9 @@ Layout make_layout(const ekf_config& c) {
         L.xl_len = L.xl_stag + 256;
         L.off_xl = take(2 * L.xl_len * 8);
         L.off_done = take(256);
+        L.off_sync = take(256);
+        L.wsup_ld = (int)round_up(EKF_CAM + (int64_t)L.lmd * c.max_visible, 32);
+        L.off_wsup = take((size_t)L.kmax * L.wsup_ld * L.elem);
     }
     L.total = o;
     return L;
@@ -135,6 +139,8 @@ struct ekf_filter {
     bool debug_w = false;
     uint64_t fseq = 0;         // FUSED frames enqueued since reset: parity of the exchange buffer, frame tag
     uint64_t done_total = 0;   // column chunks of fused frames enqueued since reset
+    uint64_t la_base = 0;      // frames that went through the pipelined sequence mode since reset (device counters)
+    int la_ok = -1;            // pipelined mode usable (-1: not probed yet; 0: the two streams share a hardware queue)
     // pinned staging ring for host-pointer observes
     char* pinned = nullptr;
     size_t slot_bytes = 0;
@@ -306,6 +312,8 @@ int sync_and_check(ekf_filter* f, int state_count = 0) {
         if (st & (EKF_ST_STALE_JAC | EKF_ST_STALE_COL | EKF_ST_STALE_S))
             return fail(EKF_ERR_NUMERIC, "internal: exchange data of another frame accepted in the front kernel (status " +
                                              std::to_string(st) + ")");
+        if (st & EKF_ST_GATE_TIMEOUT)
+            return fail(EKF_ERR_NUMERIC, "internal: a device-side wait between the two streams of the pipelined sequence mode timed out");
         if (st & EKF_ST_TIMEOUT)   // a bounded wait inside the fused front kernel ran out (should never happen)
             return fail(EKF_ERR_NUMERIC, "internal: exchange wait timed out in the front kernel (status " +
                                              std::to_string(st) + ")");
@@ -451,6 +459,7 @@ int ekf_reset(ekf_filter* f, const double initial_camera_pose[10]) {
                               L.xl_len * 4, f->stream));
     f->fseq = 0;
     f->done_total = 0;
+    f->la_base = 0;
     HIP_TRY(hipMemcpyAsync(f->state, initial_camera_pose, 10 * sizeof(double), hipMemcpyHostToDevice,
                            f->stream));
     // P = 0.1 I_10  (extended_kalman_filter.py:48)
@@ -563,11 +572,31 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
     if (m > f->cfg.max_visible) return fail(EKF_ERR_CAPACITY, "more detections than max_visible");
     if (!lm_index_dev || !z_dev) return fail(EKF_ERR_INVALID, "NULL detections");
     if (f->n_lm < 1) return fail(EKF_ERR_STATE, "observe before any landmark was added");
-    // opt-in only: every cross-stream event costs a few us of bubble and the two streams compete for
-    // the CUs; measured slower than the serial order at every size since the front kernel is fused
-    // (n=1024: 17.6k vs 19.0k updates/s, n=4096: 1.69k vs 1.90k)
-    const bool want = (f->cfg.flags & 2) != 0;
-    const bool lookahead = want && !f->timing && frames >= 2;
+    // Pipelined mode (F(t+1) beside C(t), see below): flags bit 1 forces it, bit 0 forbids it, otherwise it is
+    // chosen where it was measured to win (tools/pipeline_sweep.py, f32 covariance, us per frame pipelined / serial:
+    // n=512 m=32 34.3 / 33.0 - n=1024 m=32 36.0 / 41.3 - n=2048 m=32 65.8 / 74.8 - n=2048 m=64 130.9 / 181.9 -
+    // n=4096 m=64 475 / 442; f64: the priority rows have no MFMA kernel, no gain)
+    const int dims_now = f->dims();
+    const bool auto_on = f->cfg.cov_dtype == EKF_COV_F32 && f->cfg.cov_kernel != EKF_COVK_VALU && dims_now >= 2400 && dims_now <= 9000;
+    const bool want = (f->cfg.flags & 2) != 0 || ((f->cfg.flags & 1) == 0 && auto_on);
+    bool lookahead = want && !f->timing && frames >= 2 && (f->cfg.flags & 4) == 0;     // (fused front kernel only)
+    if (lookahead && f->la_ok < 0) {
+        // The device-side gates need the two streams on DIFFERENT hardware queues (HIP maps streams to a small pool
+        // of queues): a gate that shares its queue with the launch it waits for would wait for ever.  Probe once: a
+        // gate on the internal stream, the matching signal on the handle's stream, a short poll budget.
+        unsigned long long* probe = f->at<unsigned long long>(f->lay.off_sync) + 2;
+        int32_t* pstat = f->at<int32_t>(f->lay.off_sync) + 8;
+        HIP_TRY(hipMemsetAsync(probe, 0, 16, f->stream));
+        HIP_TRY(hipStreamSynchronize(f->stream));
+        ekf_launch_gate(probe, 1ull, pstat, f->big, 1 << 14);
+        ekf_launch_signal(probe, 1ull, f->stream);
+        HIP_TRY(hipStreamSynchronize(f->big));
+        HIP_TRY(hipStreamSynchronize(f->stream));
+        int32_t ps = 0;
+        HIP_TRY(hipMemcpy(&ps, pstat, 4, hipMemcpyDeviceToHost));
+        f->la_ok = (ps == 0) ? 1 : 0;
+    }
+    if (lookahead && f->la_ok == 0) lookahead = false;
     if (!lookahead) {
         for (int t = 0; t < frames; ++t) {
             rc = enqueue_frame(f, lm_index_dev + (size_t)t * m, z_dev + (size_t)t * m * f->lay.rd, m,
@@ -576,47 +605,69 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
         }
         return EKF_OK;
     }
-    // Cross-frame lookahead.  Main stream: gather, solve, panel and the priority rows of every
-    // frame; internal stream: the big covariance update.  Frame t+1's gather reads its support
-    // rows of P_{t+1} from the priority-row buffer, so it only waits for frame t's small kernels.
+    // Pipelined sequence mode.  Stream A (the handle's): front kernel F(t), priority rows R(t) -- the rows of
+    // P_{t+1} that F(t+1) reads, so F(t+1) does not wait for the big update.  Stream B (internal): the covariance
+    // update C(t), which then runs BESIDE F(t+1).  Edges between the streams are ordered on the device:
+    //   R(t) complete  -> C(t) may start : F(t+1) stores "t+1 started" when it starts (it follows R(t) on stream
+    //                     A); a one-wave gate kernel in front of C(t) on stream B polls that counter;
+    //   C(t) complete  -> R(t+1) may read P : a one-thread kernel behind C(t) bumps a second counter; F(t+1) does
+    //                     not finish before it has seen it (its measurement workgroup polls at its end), and
+    //                     R(t+1) follows F(t+1) on stream A.
+    // Kernel boundaries on each stream give the memory ordering; the counters only carry "that launch is over".
+    // Every wait is bounded.  The front kernel claims (almost) all LDS of its CUs, so the covariance update's
+    // workgroups run on the other CUs instead of next to the pivot chain.
     const Layout& L = f->lay;
     const bool f32 = f->cfg.cov_dtype == EKF_COV_F32;
     const int variant = f->cfg.cov_kernel == EKF_COVK_VALU ? 1 : 2;
     void* wbuf[2] = {f->at<void>(L.off_wpanel), f->at<void>(L.off_wpanel2)};
     void* prow = f->at<void>(L.off_prow);
+    unsigned long long* sync = f->at<unsigned long long>(L.off_sync);
+    int32_t* status = f->at<int32_t>(L.off_status);
+    const uint64_t base = f->la_base;
+    // The front kernel claims (almost) all LDS of its CUs while it has few workgroups (n=1024, m=32: 72 on 256
+    // CUs: 36.0 us per frame with the claim, 38.5 without); with a grid that approaches the CU count the claim only
+    // keeps the covariance update waiting (n=2048, m=32: 73.6 with, 65.8 without).
+    static const char* la_env = getenv("EKF_LA_LDS_KB");          // (experiments)
+    const int nb_now = (int)round_up(L.rd * m, EKF_RB) / EKF_RB;
+    const int grid_now = nb_now * (nb_now + 1) / 2 + 2 + (int)round_up(f->dims(), 128) / 64;
+    const int la_lds = la_env ? atoi(la_env) * 1024 : (grid_now <= 100 ? 148 * 1024 : 0);
+    // stream B starts from everything that is on stream A now (the previous call ended with the reverse join)
+    HIP_TRY(hipEventRecord(f->ev_small[0], f->stream));
+    HIP_TRY(hipStreamWaitEvent(f->big, f->ev_small[0], 0));
     for (int t = 0; t < frames; ++t) {
         const int par = t & 1;
         EkfFrame fr = make_frame(f, lm_index_dev + (size_t)t * m, z_dev + (size_t)t * m * L.rd, m,
                                  trajectory_dev ? trajectory_dev + (size_t)t * 7 : nullptr);
         fr.wpanel = wbuf[par];
         fr.prow = (t > 0) ? prow : nullptr;
-        if (use_front_kernel(f, fr)) {
-            bind_exchange(f, fr);
-            if (f32) ekf_launch_front<float>(fr, f->stream); else ekf_launch_front<double>(fr, f->stream);
-        } else {
-            if (f32) ekf_launch_gather<float>(fr, f->stream); else ekf_launch_gather<double>(fr, f->stream);
-            ekf_launch_solve(fr, f->stream);
-            if (f32) ekf_launch_panel<float>(fr, f->stream); else ekf_launch_panel<double>(fr, f->stream);
-            if (fr.model == 1) ekf_launch_inject_rot(fr, f->n_lm, f->stream);
-        }
-        if (t + 1 < frames) {
-            // the rows below are read from P_t: the big update of frame t-1 must be complete
-            // (this also frees the W panel that frame t+1 will overwrite)
-            if (t > 0) HIP_TRY(hipStreamWaitEvent(f->stream, f->ev_big[(t - 1) & 1], 0));
+        fr.la_sync = sync;
+        fr.la_signal = (t > 0) ? base + (uint64_t)t : 0;       // "F(t) has started": R(t-1) is complete
+        fr.la_gate = (t > 0) ? base + (uint64_t)t : 0;         // C(t-1) complete before F(t) ends
+        fr.lds_min = la_lds;
+        if (t + 1 < frames) {                                  // the next frame's detections: support rows of R(t)
             fr.next_idx = lm_index_dev + (size_t)(t + 1) * m;
             fr.next_m = m;
+            fr.wsup = f->at<void>(L.off_wsup);
+            fr.wsup_ld = L.wsup_ld;
+        }
+        bind_exchange(f, fr);
+        if (f32) ekf_launch_front<float>(fr, f->stream); else ekf_launch_front<double>(fr, f->stream);
+        if (t + 1 < frames) {
             fr.prow_out = prow;
             if (f32) ekf_launch_cov_rows<float>(fr, f->stream); else ekf_launch_cov_rows<double>(fr, f->stream);
+        } else {
+            ekf_launch_signal(sync, base + (uint64_t)frames, f->stream);     // no F(t+1) to say that F(t) is over
         }
-        HIP_TRY(hipEventRecord(f->ev_small[par], f->stream));
-        HIP_TRY(hipStreamWaitEvent(f->big, f->ev_small[par], 0));
+        ekf_launch_gate(sync, base + (uint64_t)t + 1, status, f->big);
         if (f32) ekf_launch_cov_update<float>(fr, variant, f->big);
         else ekf_launch_cov_update<double>(fr, variant, f->big);
-        HIP_TRY(hipEventRecord(f->ev_big[par], f->big));
+        ekf_launch_signal(sync + 1, base + (uint64_t)t + 1, f->big);
         HIP_TRY(hipGetLastError());
     }
+    f->la_base = base + (uint64_t)frames;
     // join: everything later on the main stream (and every getter) sees the final covariance
-    HIP_TRY(hipStreamWaitEvent(f->stream, f->ev_big[(frames - 1) & 1], 0));
+    HIP_TRY(hipEventRecord(f->ev_big[0], f->big));
+    HIP_TRY(hipStreamWaitEvent(f->stream, f->ev_big[0], 0));
     f->last_m = m;
     return EKF_OK;
 }

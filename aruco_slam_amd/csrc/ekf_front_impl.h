@@ -198,6 +198,9 @@ __device__ __forceinline__ void fr_role_measure(const EkfFrame& fr, double* sm) 
     double* rsd = sm + fr.k * JC;                       // [kpad]
     int* lmc = reinterpret_cast<int*>(rsd + fr.kpad);
     const int tid = threadIdx.x;
+    // pipelined sequence mode: this launch has started, i.e. everything before it on its stream is complete
+    if (fr.la_signal && tid == 0)
+        __hip_atomic_store(fr.la_sync, fr.la_signal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     double cam[EKF_CAM];
 #pragma unroll
     for (int a = 0; a < EKF_CAM; ++a) cam[a] = fr.state[a];
@@ -215,6 +218,15 @@ __device__ __forceinline__ void fr_role_measure(const EkfFrame& fr, double* sm) 
         ekf_stc(fr.xl + fr.xl_tag + 16, fr.seqno);         // residual
     }
     if (fr.stamps && tid == 0) fr.stamps[55] = wall_clock64();
+    // pipelined sequence mode: keep this launch open until the covariance update of the previous frame (other
+    // stream) is complete -- whatever follows this launch on its stream may then read P
+    if (fr.la_gate && tid == 0) {
+        int it = 0;
+        while (__hip_atomic_load(fr.la_sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < fr.la_gate) {
+            if (++it > (1 << 22)) { atomicOr(fr.status, EKF_ST_GATE_TIMEOUT); break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -368,6 +380,25 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
     const double* __restrict__ xy = fr.xl + fr.xl_y;
     long long* stp = (fr.stamps && col0 == 0 && lane == 0) ? fr.stamps + 34 : nullptr;
     T* __restrict__ wp = static_cast<T*>(fr.wpanel);
+    // pipelined sequence mode: the columns of W that the NEXT frame's priority rows need (its support rows:
+    // camera + every next-frame detection's landmark) are also written compactly, W_sup[k][slot], so that the
+    // priority-row kernel reads its A operand coalesced instead of gathering 96 x 106 scattered words per tile.
+    // smask: next-frame detections whose landmark owns this lane's column (duplicates possible); cslot: camera slot
+    T* __restrict__ wsup = static_cast<T*>(fr.wsup);
+    unsigned long long smask = 0ull;
+    int sdim = 0;
+    const int mycol = col0 + j;
+    const int cslot = (wsup && mycol < EKF_CAM) ? mycol : -1;
+    if (wsup && mycol >= EKF_CAM && mycol < fr.dims) {
+        constexpr int LMD = EkfModel<MODEL>::LMD;
+        const int li = (mycol - EKF_CAM) / LMD;
+        sdim = (mycol - EKF_CAM) % LMD;
+        for (int jj = 0; jj < fr.next_m; ++jj) {
+            int ni = fr.next_idx[jj];
+            if ((unsigned)ni >= (unsigned)fr.n_lm) ni = 0;
+            if (ni == li) smask |= 1ull << jj;
+        }
+    }
     pf64x4 t[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b)
@@ -446,6 +477,12 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
             const int row = 16 * q + g + 4 * r;
             wp[(int64_t)row * fr.ldw + col0 + j] = (T)wq[r];
             if (fr.wdbg) fr.wdbg[(int64_t)row * fr.ldw + col0 + j] = wq[r];
+            if (cslot >= 0) wsup[(int64_t)row * fr.wsup_ld + cslot] = (T)wq[r];
+            for (unsigned long long mm = smask; mm; mm &= mm - 1) {
+                constexpr int LMD = EkfModel<MODEL>::LMD;
+                const int jj = __builtin_ctzll(mm);
+                wsup[(int64_t)row * fr.wsup_ld + EKF_CAM + LMD * jj + sdim] = (T)wq[r];
+            }
         }
         // t[i] += (-L_iq) W_q for i > q, at most LG blocks of -L in registers at a time (the whole
         // kernel has to stay clear of register spills)
@@ -669,6 +706,7 @@ static void ekf_front_go(const EkfFrame& fr, hipStream_t s) {
     const size_t lds_f = (size_t)sv_lds_doubles(NB) * 8;
     size_t lds = lds_s > lds_c ? lds_s : lds_c;
     if (lds_f > lds) lds = lds_f;
+    if ((size_t)fr.lds_min > lds) lds = (size_t)fr.lds_min;
     hipLaunchKernelGGL((ekf_front_kernel<T, NU, MODEL, NB>), dim3(nS + 2 + fr.ncols / 64), dim3(FR_T), lds, s, fr);
 }
 

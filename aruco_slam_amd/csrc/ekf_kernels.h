@@ -11,6 +11,7 @@
 #define EKF_ST_STALE_COL 32       // a chunk accepted a factor block column that carries another frame's tag
 #define EKF_ST_STALE_S 64         // the factorisation accepted an S block / residual that carries another frame's tag
 #define EKF_ST_BAD_INDEX 128      // a landmark index outside [0, n_lm) reached a kernel (clamped to 0 there)
+#define EKF_ST_GATE_TIMEOUT 256   // pipelined sequence mode: a device-side wait for the other stream ran out
 
 // Everything one frame's kernels need; passed by value.
 struct EkfFrame {
@@ -58,6 +59,15 @@ struct EkfFrame {
     int32_t next_m;
     void* prow_out;            // written by ekf_launch_cov_rows (cov dtype)
     const void* prow;          // read by the gather kernel; null = read P
+    // device-side cross-stream ordering of the pipelined sequence mode (ekf_api.hip: run_pipelined):
+    // la_sync[0] = "front kernel of frame n has started" counter, la_sync[1] = "covariance update of frame n is
+    // complete" counter.  A front kernel stores la_signal into [0] when it starts (0 = no) and does not
+    // finish before [1] >= la_gate (0 = no gate).
+    unsigned long long* la_sync;
+    unsigned long long la_signal, la_gate;
+    int32_t lds_min;           // front kernel: claim at least this much LDS (keeps other kernels' workgroups off its CUs)
+    void* wsup;                // pipelined mode: W[:, support rows of the next frame], [kpad][wsup_ld] in cov dtype (null: none)
+    int32_t wsup_ld;
     EkfNoise nz;
     int32_t quat_mode;
     // fused front kernel (ekf_front_impl.h): exchange buffers between its workgroups.  ONE buffer per
@@ -104,6 +114,10 @@ template <typename T> void ekf_launch_panel(const EkfFrame& fr, hipStream_t s);
 template <typename T> void ekf_launch_cov_update(const EkfFrame& fr, int variant, hipStream_t s,
                                                  hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 template <typename T> void ekf_launch_cov_rows(const EkfFrame& fr, hipStream_t s);
+// pipelined sequence mode: one-wave kernels that order the two streams on the device
+void ekf_launch_gate(unsigned long long* counter, unsigned long long target, int32_t* status, hipStream_t s,
+                     int max_polls = 1 << 22);
+void ekf_launch_signal(unsigned long long* counter, unsigned long long value, hipStream_t s);
 
 template <typename T>
 void ekf_launch_add_markers(void* cov, int64_t ld, double* state, int32_t dims,

@@ -128,7 +128,7 @@ class HipEkf:
                          "scalar_first": EKF_QUAT_SCALAR_FIRST}[quat_mode]
         kern = {"auto": EKF_COVK_AUTO, "valu": EKF_COVK_VALU, "mfma": EKF_COVK_MFMA}
         cfg.cov_kernel = kern[cov_kernel]
-        cfg.flags = {None: 0, False: 1, True: 2}[lookahead]   # None / False: serial order (default)
+        cfg.flags = {None: 0, False: 1, True: 2}[lookahead]   # None: pipelined sequence mode where it wins (by size); False: never; True: always
         if not fused:
             cfg.flags |= 4        # separate gather / solve / panel launches
         self.fused = bool(fused)  # ("force" of earlier versions == True: there is no automatic fallback any more)

@@ -49,7 +49,7 @@ def parse_args():
     ap.add_argument("--cov-dtype", default="float32", choices=["float32", "float64"])
     ap.add_argument("--cov-kernel", default="auto", choices=["auto", "valu", "mfma"])
     ap.add_argument("--lookahead", choices=["auto", "on", "off"], default="auto",
-                    help="cross-frame lookahead of the sequence entry point (auto = off)")
+                    help="pipelined sequence mode: front kernel of frame t+1 beside the covariance update of frame t (auto = by size)")
     ap.add_argument("--unfused", action="store_true",
                     help="gather / solve / panel as separate launches instead of the fused front kernel")
     ap.add_argument("--cpu-frames", type=int, default=12,
@@ -271,7 +271,10 @@ def main():
         "config": {"workload": f"n={n} landmarks, m={m} visible/frame, N={dims}, k={3 * m}, "
                                f"{args.cov_dtype} covariance, one independent sequence per GPU",
                    "sequences": world, "cov_kernel": args.cov_kernel,
-                   "front": "stage kernels" if args.unfused else "fused front kernel"},
+                   "front": "stage kernels" if args.unfused else "fused front kernel",
+                   "sequence_mode": {"auto": "pipelined where it wins (f32 covariance, 2400 <= N <= 9000: front kernel of "
+                                             "frame t+1 beside the covariance update of frame t), else serial",
+                                     "on": "pipelined", "off": "serial"}[args.lookahead]},
         "roofline": dict(rl_primary, **{
                      "kernel": "ekf_cov_update (P <- P + Q - W^T W)",
                      "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS},

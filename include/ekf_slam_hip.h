@@ -65,10 +65,11 @@ typedef struct ekf_config {
     int32_t cov_kernel;     /* EKF_COVK_*: covariance-update kernel */
     int32_t model;          /* EKF_MODEL_* */
     int32_t reserved;
-    int32_t flags;          /* bit 1: cross-frame lookahead in ekf_observe_sequence_device (priority rows +
-                             * covariance update on a second stream; same results, currently slower than
-                             * the serial order at every size, off by default; bit 0 is ignored).  bit 2: run gather / solve / panel as three separate
-                             * launches instead of the fused front kernel (same results, bit for bit).  bit 3 is ignored. */
+    int32_t flags;          /* bits 0-1: pipelined mode of ekf_observe_sequence_device (the front kernel of frame t+1 runs
+                             * beside the covariance update of frame t; same results, bit for bit): 0 = chosen by size
+                             * (on for an f32 covariance of 2400..9000 state dimensions), bit 0 = never, bit 1 = always.
+                             * bit 2: run gather / solve / panel as three separate launches instead of the fused front
+                             * kernel (same results, bit for bit; no pipelined mode).  bit 3 is ignored. */
     /* noise constants, defaults = extended_kalman_filter.py:21-27 */
     double initial_camera_uncertainty;   /* 0.1  */
     double initial_landmark_uncertainty; /* 0.7  */
@@ -128,10 +129,12 @@ int ekf_observe_device(ekf_filter *f, const int32_t *lm_index_dev,
  * lm_index_dev [frames,m], z_dev [frames,m,3]; after every frame the camera
  * pose state[0:7] is appended to trajectory_dev [frames,7] (may be NULL).
  * Because the next frame's detections are known, the rows of the updated
- * covariance that frame t+1 reads are produced first by a small kernel, and the
- * big covariance update of frame t runs on an internal second stream while
- * frame t+1's gather/solve/panel proceed (same arithmetic per element: results
- * are bitwise those of per-frame ekf_observe calls). */
+ * covariance that frame t+1 reads can be produced first by a small kernel, and the
+ * big covariance update of frame t then runs on an internal second stream beside
+ * frame t+1's front kernel (pipelined mode, see ekf_config.flags; the two streams are ordered
+ * by one-wave gate kernels on the device, every wait bounded; same arithmetic per element:
+ * results are bitwise those of per-frame ekf_observe calls).  The call returns with the
+ * handle's stream waiting for the internal one. */
 int ekf_observe_sequence_device(ekf_filter *f, const int32_t *lm_index_dev,
                                 const double *z_dev, int32_t m, int32_t frames,
                                 double *trajectory_dev);

@@ -315,6 +315,39 @@ def test_resident_sequence_entry_matches_per_frame_calls(dtype, kernel):
             assert np.array_equal(a, b)
 
 
+def test_pipelined_sequence_mode_at_headline_size_is_bitwise_the_serial_order():
+    """n=1024, m=32, f32 covariance: the sequence entry point picks the pipelined mode by itself here (front kernel
+    of frame t+1 beside the covariance update of frame t, priority rows by MFMA from the compact support columns,
+    device-side gates between the two streams).  Three calls back to back (join / restart of the pipeline), a
+    duplicate detection and a frame that sees one landmark in every slot; state, covariance and trajectory must be
+    the bits of the serial order, and no status bit may be set."""
+    import torch
+    from aruco_slam_amd.synthetic import SyntheticStream
+    n, m = 1024, 32
+    s = SyntheticStream(n, m, seed=9)
+    boot = list(s.bootstrap())
+    frames = [(ids.copy(), poses.copy()) for ids, poses in s.steady(70)]
+    frames[11][0][5] = frames[11][0][1]
+    frames[40][0][:] = frames[40][0][0]
+    idx = torch.tensor(np.stack([f[0] for f in frames]), dtype=torch.int32, device="cuda")
+    z = torch.tensor(np.stack([f[1][:, :3] for f in frames]), dtype=torch.float64, device="cuda")
+    outs = []
+    for mode in (None, False, True):                 # by size (= pipelined here), never, always
+        flt = _ekf(max_landmarks=n, max_visible=m, cov_dtype="float32", lookahead=mode)
+        for ids, poses in boot:
+            flt.observe(ids, poses)
+        traj = torch.zeros((len(frames), 7), dtype=torch.float64, device="cuda")
+        for lo, hi in ((0, 30), (30, 31), (31, 70)):
+            flt.backend.observe_sequence(idx[lo:hi], z[lo:hi], traj[lo:hi])
+        flt.backend.sync()
+        outs.append((traj.cpu().numpy(), flt.state, flt.uncertainty))
+        del flt
+    assert np.isfinite(outs[0][2]).all()
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert np.array_equal(a, b)
+
+
 def test_error_behaviour():
     from aruco_slam_amd.hip_backend import EkfError
     flt = _ekf(max_landmarks=4, max_visible=2)
