@@ -31,6 +31,22 @@
 #include <hip/hip_ext.h>
 #include "ekf_kernels.h"
 
+// Stores of the updated covariance.  P is not read again inside the launch and every XCD's L2 is invalidated before the
+// next launch reads it, so keeping the 38.5 MB (n=1024) of written lines dirty in the L2s only postpones their way to
+// memory to the end of the launch, where the next kernel waits for it.  Write-through (sc1) stores stream them out while
+// the kernel still computes (tools/store_mode_probe.sh, n=1024, m=32, f32; kernel / serial frame / pipelined frame in us:
+// plain 16.7 / 40.0 / 36.1 - nontemporal 15.9 / 39.2 / 35.2 - write-through 15.2 / 38.1 / 34.6).
+// EKF_COV_STORE_MODE (experiments): 0 plain, 1 nontemporal, 2 write-through.
+#ifndef EKF_COV_STORE_MODE
+#define EKF_COV_STORE_MODE 2
+#endif
+template <typename T>
+__device__ __forceinline__ void ekf_cov_store(T* p, T v) {
+    if (EKF_COV_STORE_MODE == 1) __builtin_nontemporal_store(v, p);
+    else if (EKF_COV_STORE_MODE == 2) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
@@ -192,7 +208,7 @@ void ekf_cov_update_mfma_f32(EkfFrame fr, int nitems) {
 #undef EKF_WAIT16
     const float qlane = (I == J) ? (float)ekf_qdiag(i0 + l31, fr.dims, fr.nz) : 0.0f;
     float out[16];
-    auto stf = [](float* base, unsigned off, float v) { *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off) = v; };
+    auto stf = [](float* base, unsigned off, float v) { ekf_cov_store(reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off), v); };
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         const int rl = (reg & 3) + 8 * (reg >> 2) + 4 * lhi;
@@ -277,7 +293,7 @@ __global__ __launch_bounds__(256) void ekf_cov_update_mfma_f64(EkfFrame fr, int 
                 double v = pt[ri][ci][r];
                 if (I == J && rl == cl) v += ekf_qdiag(i0 + rl, fr.dims, fr.nz);
                 v += acc[ri][ci][r];
-                P[(int64_t)(i0 + rl) * ld + j0 + cl] = v;
+                ekf_cov_store(P + (int64_t)(i0 + rl) * ld + j0 + cl, v);
                 if (I != J) tr[wave][rl][cl] = v;
             }
     if (I != J) {
@@ -286,7 +302,7 @@ __global__ __launch_bounds__(256) void ekf_cov_update_mfma_f64(EkfFrame fr, int 
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int cc = 2 * it + lhi;
-            P[(int64_t)(j0 + cc) * ld + i0 + l31] = tr[wave][l31][cc];
+            ekf_cov_store(P + (int64_t)(j0 + cc) * ld + i0 + l31, tr[wave][l31][cc]);
         }
     }
 }
@@ -332,14 +348,14 @@ __global__ __launch_bounds__(256) void ekf_cov_update_mfma_f64_split(EkfFrame fr
         double v = pt[r];
         if (I == J && rl == cl) v += ekf_qdiag(i0 + rl, fr.dims, fr.nz);
         v += acc[r];
-        P[(int64_t)(i0 + rl) * ld + j0 + cl] = v;
+        ekf_cov_store(P + (int64_t)(i0 + rl) * ld + j0 + cl, v);
         if (I != J) tr[rl][cl] = v;
     }
     if (I != J) {
         __syncthreads();
         const int l31 = threadIdx.x & 31;
         for (int cc = threadIdx.x >> 5; cc < 32; cc += 8)          // column cc of D = row of D^T
-            P[(int64_t)(j0 + cc) * ld + i0 + l31] = tr[l31][cc];
+            ekf_cov_store(P + (int64_t)(j0 + cc) * ld + i0 + l31, tr[l31][cc]);
     }
 }
 
@@ -426,8 +442,8 @@ __global__ __launch_bounds__(256) void ekf_cov_rows_mfma_f32(EkfFrame fr, int ns
         rowmap[threadIdx.x] = (slot < EKF_CAM) ? slot : (slot < nslots ? lrow : 0);
     }
     __syncthreads();
-    if (!tile_ok) return;
     auto row_of = [&](int slot) { return rowmap[slot - 128 * blockIdx.y]; };
+    if (tile_ok) {
     // C / D layout: register reg <-> tile row (reg & 3) + 8 (reg >> 2) + 4 lhi, column l31
     float pt[16];
     int prow_of[16];
@@ -455,7 +471,18 @@ __global__ __launch_bounds__(256) void ekf_cov_rows_mfma_f32(EkfFrame fr, int ns
     for (int reg = 0; reg < 16; ++reg) {
         const int slot = 32 * tile_i + (reg & 3) + 8 * (reg >> 2) + 4 * lhi;
         const float q = (prow_of[reg] == j0 + l31) ? (float)ekf_qdiag(prow_of[reg], fr.dims, fr.nz) : 0.0f;
-        if (slot < nslots) out[(int64_t)slot * ldw + j0 + l31] = (pt[reg] + q) + acc[reg];
+        if (slot < nslots) ekf_cov_store(out + (int64_t)slot * ldw + j0 + l31, (pt[reg] + q) + acc[reg]);
+    }
+    }
+    // pipelined sequence mode: once EVERY workgroup has read its rows of P, the covariance update (other stream) may
+    // overwrite P -- the last workgroup to get here says so (the next front kernel says it again when it starts)
+    if (fr.la_signal) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long old = __hip_atomic_fetch_add(fr.la_sync + 4, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old + 1 == fr.la_gate)       // (la_gate: cumulative number of workgroups of all priority-row launches so far)
+                __hip_atomic_store(fr.la_sync, fr.la_signal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 

@@ -233,8 +233,11 @@ __device__ __forceinline__ void fr_role_measure(const EkfFrame& fr, double* sm) 
 // role: factorisation = the shared register-resident Cholesky (ekf_solve_device.h: sv_factor) with the
 // exchange buffer as input and output
 // ---------------------------------------------------------------------------------------------
-// IO policy.  Input: the wave's S blocks (OP memory order, 2 KB each: two 16-byte coherent loads per
-// lane, ekf_ldc16 -- the atomic builtins stop at 8 bytes) and, for the wave that owns the residual
+// IO policy.  Input: the wave's S blocks (OP memory order, 2 KB each: four 8-byte coherent loads per lane,
+// all blocks of the wave in flight together.  16-byte loads would halve the instruction count, but the two ways
+// to get them are both out: inline asm (the compiler copied destination registers between issue and wait:
+// tools/asm_load_hazards.py) and volatile accesses (`global_load_dwordx4 sc0 sc1`, but LLVM puts an
+// `s_waitcnt vmcnt(0)` behind every volatile load: one round trip per load, 1.1 us per block) and, for the wave that owns the residual
 // row, z - h.  Polling touches ONE word per row (the last word of the row's first block: the S-block
 // workgroups all finish at about the same time); correctness does not depend on it: every word is
 // checked against the sentinel after the bulk has arrived and fetched again until it has landed.
@@ -268,65 +271,86 @@ struct SvIoFused {
         }
         return v;
     }
-    template <int NB, int N0, int N1>
-    __device__ __forceinline__ void load_all(sf64x4 (&z0)[N0], sf64x4 (&z1)[N1], int i0, int i1, bool has0, bool has1,
-                                             int lane, int g) {
+    // Block columns [C0, C1) of the wave's rows into registers (and, with C0 == 0, the whole residual row if the
+    // wave owns it).  One polled word per block (its last), all polls of a round in flight together; then tags and
+    // bulk, all in flight together; then the per-word sentinel check.  Branch-free issue: block indices are clamped
+    // instead of guarded, so that the loads of a round sit in one basic block and all go out before the first
+    // result is needed (guarded loads were waited for one by one: ~1.2 us per block).
+    template <int NB, int N0, int N1, int C0, int C1>
+    __device__ __forceinline__ void load_cols(sf64x4 (&z0)[N0], sf64x4 (&z1)[N1], int i0, int i1, bool has0, bool has1,
+                                              int lane, int g) {
         const bool blk0 = has0 && i0 < NB, blk1 = has1 && i1 < NB;       // S-block rows (not the residual)
-        {   // one polled word per row of the wave
-            const double* w0 = blk0 ? fr.xs + sv_blk_index(i0, 0) + 255 : fr.xr + 15;
-            const double* w1 = blk1 ? fr.xs + sv_blk_index(i1, 0) + 255 : w0;
+        const bool res0 = C0 == 0 && has0 && i0 == NB, res1 = C0 == 0 && has1 && i1 == NB;
+        const int r0 = blk0 ? i0 : 0, r1 = blk1 ? i1 : r0;
+        if (C0 == 0) {      // (the later block columns are fetched beside the first chain, ~1.5 us after these have been seen:
+                            // no polling round for them, a straggler goes down the settle path)
+            const double* wr = (res0 || res1) ? fr.xr + 15 : fr.xs + sv_blk_index(r0, min(C0, r0)) + 255;
             int it = 0;
-            if (has0)
-                for (;;) {
-                    const bool pend = (int)ekf_is_sent(ekf_ldc(w0)) | (int)ekf_is_sent(ekf_ldc(w1));       // (no short circuit: loads together)
-                    if (!pend) break;
-                    if (++it > EKF_SPIN_MAX) { spin_fail = 1; break; }
-                    ekf_poll_sleep();
-                }
+            for (;;) {
+                int pend = (int)ekf_is_sent(ekf_ldc(wr));
+#pragma unroll
+                for (int tc = C0; tc < N0 && tc < C1; ++tc) pend |= (int)ekf_is_sent(ekf_ldc(fr.xs + sv_blk_index(r0, min(tc, r0)) + 255));
+#pragma unroll
+                for (int tc = C0; tc < N1 && tc < C1; ++tc) pend |= (int)ekf_is_sent(ekf_ldc(fr.xs + sv_blk_index(r1, min(tc, r1)) + 255));
+                if (!pend) break;
+                if (++it > EKF_SPIN_MAX) { spin_fail = 1; break; }
+                ekf_poll_sleep();
+            }
         }
-        // frame tags of the blocks (compiler-visible loads, issued before -- hence older than -- the bulk)
         double t0[N0], t1[N1];
 #pragma unroll
-        for (int tc = 0; tc < N0; ++tc) t0[tc] = (blk0 && tc <= i0) ? ekf_ldc(fr.xs_tag + 16 * tc + i0) : fr.seqno;
+        for (int tc = C0; tc < N0 && tc < C1; ++tc) t0[tc] = ekf_ldc(fr.xs_tag + 16 * min(tc, r0) + r0);
 #pragma unroll
-        for (int tc = 0; tc < N1; ++tc) t1[tc] = (blk1 && tc <= i1) ? ekf_ldc(fr.xs_tag + 16 * tc + i1) : fr.seqno;
+        for (int tc = C0; tc < N1 && tc < C1; ++tc) t1[tc] = ekf_ldc(fr.xs_tag + 16 * min(tc, r1) + r1);
+        sf64x4 y0[N0], y1[N1];
 #pragma unroll
-        for (int tc = 0; tc < N0; ++tc)
+        for (int tc = C0; tc < N0 && tc < C1; ++tc) {
+            const double* p0 = fr.xs + sv_blk_index(r0, min(tc, r0)) + 2 * lane;
+            y0[tc] = sf64x4{ekf_ldc(p0), ekf_ldc(p0 + 1), ekf_ldc(p0 + 128), ekf_ldc(p0 + 129)};
+        }
+#pragma unroll
+        for (int tc = C0; tc < N1 && tc < C1; ++tc) {
+            const double* p0 = fr.xs + sv_blk_index(r1, min(tc, r1)) + 2 * lane;
+            y1[tc] = sf64x4{ekf_ldc(p0), ekf_ldc(p0 + 1), ekf_ldc(p0 + 128), ekf_ldc(p0 + 129)};
+        }
+#pragma unroll
+        for (int tc = C0; tc < N0 && tc < C1; ++tc)
             if (blk0 && tc <= i0) {
-                const double* p0 = fr.xs + sv_blk_index(i0, tc) + 2 * lane;
-                const sv_d2 a = ekf_ldc16(p0), b = ekf_ldc16(p0 + 128);
-                z0[tc] = sf64x4{a[0], a[1], b[0], b[1]};
-            }
-#pragma unroll
-        for (int tc = 0; tc < N1; ++tc)
-            if (blk1 && tc <= i1) {
-                const double* p0 = fr.xs + sv_blk_index(i1, tc) + 2 * lane;
-                const sv_d2 a = ekf_ldc16(p0), b = ekf_ldc16(p0 + 128);
-                z1[tc] = sf64x4{a[0], a[1], b[0], b[1]};
-            }
-#pragma unroll
-        for (int tc = 0; tc < N0; ++tc)
-            if (blk0 && tc <= i0) {
+                z0[tc] = y0[tc];
                 settle_block(z0[tc], i0, tc, lane);
                 stale |= fr_tag_stale(t0[tc], fr.seqno);
             }
 #pragma unroll
-        for (int tc = 0; tc < N1; ++tc)
+        for (int tc = C0; tc < N1 && tc < C1; ++tc)
             if (blk1 && tc <= i1) {
+                z1[tc] = y1[tc];
                 settle_block(z1[tc], i1, tc, lane);
                 stale |= fr_tag_stale(t1[tc], fr.seqno);
             }
-        // the residual row (one wave): z - h, replicated in all 16 rows of its "block"
-        if (has0 && i0 == NB) {
+        // the residual row (one wave): z - h, replicated in all 16 rows of its "block".  All loads first, THEN the
+        // sentinel checks (one round trip)
+        if (res0) {
 #pragma unroll
             for (int tc = 0; tc < N0; ++tc)
-                if (tc < NB) z0[tc] = fetch_resid(tc, g);
+                if (tc < NB) {
+                    const double* base = fr.xr + EKF_RB * tc + g;
+                    z0[tc] = sf64x4{ekf_ldc(base), ekf_ldc(base + 4), ekf_ldc(base + 8), ekf_ldc(base + 12)};
+                }
+#pragma unroll
+            for (int tc = 0; tc < N0; ++tc)
+                if (tc < NB && !settled(z0[tc])) z0[tc] = fetch_resid(tc, g);
             stale |= fr_tag_stale(ekf_ldc(fr.xl + fr.xl_tag + 16), fr.seqno);
         }
-        if (has1 && i1 == NB) {
+        if (res1) {
 #pragma unroll
             for (int tc = 0; tc < N1; ++tc)
-                if (tc < NB) z1[tc] = fetch_resid(tc, g);
+                if (tc < NB) {
+                    const double* base = fr.xr + EKF_RB * tc + g;
+                    z1[tc] = sf64x4{ekf_ldc(base), ekf_ldc(base + 4), ekf_ldc(base + 8), ekf_ldc(base + 12)};
+                }
+#pragma unroll
+            for (int tc = 0; tc < N1; ++tc)
+                if (tc < NB && !settled(z1[tc])) z1[tc] = fetch_resid(tc, g);
             stale |= fr_tag_stale(ekf_ldc(fr.xl + fr.xl_tag + 16), fr.seqno);
         }
     }

@@ -83,14 +83,6 @@ __device__ __forceinline__ size_t sv_blk_index(int i, int tc) { return (size_t)(
 __host__ __device__ constexpr int sv_lds_doubles(int nb) { return 512 + (nb + 1) * 256 + 64; }     // X (two slots) | L_ib of every row | flags
 
 typedef double sv_d2 __attribute__((ext_vector_type(2)));
-// 16-byte coherent load for the in-launch exchange: a volatile access through a global-address-space
-// pointer compiles to `global_load_dwordx4 ... sc0 sc1` (system scope, a superset of the agent scope
-// the 8-byte builtins give) and stays visible to the compiler -- unlike an inline-asm load, whose
-// destination registers the compiler may copy or spill before the hand-written wait (round 1 / the first
-// version of this file did that; tools/asm_load_hazards.py found real copies in flight).
-typedef const volatile sv_d2 __attribute__((address_space(1))) * sv_gld16_t;
-__device__ __forceinline__ sv_d2 ekf_ldc16(const double* p) { return *(sv_gld16_t)p; }
-
 // 1 / d for a wave-uniform d: v_rcp_f64 (about 2^-23) and one cubic step (error ~ e^3)
 __device__ __forceinline__ double sv_rcp(double d) {
     const double r0 = __builtin_amdgcn_rcp(d);
@@ -287,17 +279,22 @@ struct SvIoPlain {
         }
         return v;
     }
-    // every block (i, tc), tc <= min(i, NB - 1), of the wave's rows i0 / i1 (row NB: the residual,
-    // replicated in all 16 rows of its "block" so that it rides through the same instructions)
-    template <int NB, int N0, int N1>
-    __device__ __forceinline__ void load_all(sf64x4 (&z0)[N0], sf64x4 (&z1)[N1], int i0, int i1, bool has0, bool has1,
-                                             int lane, int g) {
+    // block columns [C0, C1) of the wave's rows i0 / i1 (block (i, tc) exists for tc <= min(i, NB - 1); row NB is the
+    // residual, replicated in all 16 rows of its "block" so that it rides through the same instructions: all of it
+    // comes with C0 == 0)
+    template <int NB, int N0, int N1, int C0, int C1>
+    __device__ __forceinline__ void load_cols(sf64x4 (&z0)[N0], sf64x4 (&z1)[N1], int i0, int i1, bool has0, bool has1,
+                                              int lane, int g) {
 #pragma unroll
-        for (int tc = 0; tc < N0; ++tc)
-            if (has0 && tc <= min(i0, NB - 1)) z0[tc] = (i0 == NB) ? load_resid(tc, g) : load_block(i0, tc, lane);
+        for (int tc = 0; tc < N0; ++tc) {
+            if (has0 && i0 == NB && C0 == 0 && tc < NB) z0[tc] = load_resid(tc, g);
+            else if (has0 && i0 < NB && tc >= C0 && tc < C1 && tc <= i0) z0[tc] = load_block(i0, tc, lane);
+        }
 #pragma unroll
-        for (int tc = 0; tc < N1; ++tc)
-            if (has1 && tc <= min(i1, NB - 1)) z1[tc] = (i1 == NB) ? load_resid(tc, g) : load_block(i1, tc, lane);
+        for (int tc = 0; tc < N1; ++tc) {
+            if (has1 && i1 == NB && C0 == 0 && tc < NB) z1[tc] = load_resid(tc, g);
+            else if (has1 && i1 < NB && tc >= C0 && tc < C1 && tc <= i1) z1[tc] = load_block(i1, tc, lane);
+        }
     }
     __device__ __forceinline__ void put_dinv(int b, const sf64x4& xop, int lane) {
 #pragma unroll
@@ -353,8 +350,11 @@ __device__ __forceinline__ void sv_factor(const EkfFrame& fr, IO& io, double* ld
     // over (barrier), [3 + 2 b] panel + urgent update over; [47 + 2 b], [48 + 2 b] the chain alone (b < 4)
     long long* stp = (fr.stamps && lane == 0) ? fr.stamps : nullptr;
     if (stp && wave == 0) stp[0] = clock64();
-    io.template load_all<NB, N0, N1>(z0, z1, i0, i1, has0, has1, lane, g);
+    // block column 0 first (all the first chain and the first panel need); the other block columns come in
+    // beside the first chain
+    io.template load_cols<NB, N0, N1, 0, 1>(z0, z1, i0, i1, has0, has1, lane, g);
     if (stp && wave == 0) stp[1] = clock64();
+    if (stp && NB <= 10) stp[24 + wave] = clock64();            // (each wave: its blocks are in registers)
     sf64x4 y0 = {0.0, 0.0, 0.0, 0.0}, y1 = {0.0, 0.0, 0.0, 0.0};      // OP(L_ib) of the wave's rows, column b
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -380,6 +380,7 @@ __device__ __forceinline__ void sv_factor(const EkfFrame& fr, IO& io, double* ld
                 }
             }
         }
+        if (b == 0) io.template load_cols<NB, N0, N1, 1, NB>(z0, z1, i0, i1, has0, has1, lane, g);
         if (b >= 1) {
             // the trailing updates of step b - 1 that were not urgent: block columns b + 2 .. of the wave's rows
 #pragma unroll

@@ -5,7 +5,7 @@ from aruco_slam_amd.synthetic import SyntheticStream
 n,m=1024,32
 s=SyntheticStream(n,m,seed=0)
 f=EKF(np.array([0,0,0,1,0,0,0,0,0,0]),max_landmarks=n,max_visible=m,cov_dtype="float32")
-f.backend.debug_enable_w()
+(f.backend.debug_enable_w if len(sys.argv) > 1 and sys.argv[1] == 'debug' else f.backend.debug_enable_stamps)()
 for ids,p in s.bootstrap(): f.observe(ids,p)
 for ids,p in s.steady(5): f.observe(ids,p)
 st=f.backend.debug_fetch("stamps",m)
@@ -15,7 +15,7 @@ us=lambda i:(st[i]-t0)/100.0
 print("fused front kernel timeline, us since the earliest stamp (100 MHz wall clock)")
 print("S-block wg0 start",us(60),"  measure wg published",us(55),"  S-block wg nS-1 stored",us(61))
 print("factor: start",us(62)," end",us(63))
-print("  cycles: blocks into registers",st[1]-st[0])
+print("  cycles: blocks into registers",st[1]-st[0], " per wave:", [int(st[24+w]-st[0]) for w in range(8)])
 for b in range(nb):
     prev = st[1] if b == 0 else st[3+2*(b-1)]
     print("  col",b," chain phase + barrier",st[2+2*b]-prev," panel + barrier + urgent update",st[3+2*b]-st[2+2*b],
