@@ -302,28 +302,27 @@ struct SvIoFused {
         for (int tc = C0; tc < N0 && tc < C1; ++tc) t0[tc] = ekf_ldc(fr.xs_tag + 16 * min(tc, r0) + r0);
 #pragma unroll
         for (int tc = C0; tc < N1 && tc < C1; ++tc) t1[tc] = ekf_ldc(fr.xs_tag + 16 * min(tc, r1) + r1);
-        sf64x4 y0[N0], y1[N1];
+        // (straight into z: entries beyond the row's last block receive a clamped duplicate that nobody reads; with
+        // C0 == 0 the residual row's entries are overwritten below)
 #pragma unroll
         for (int tc = C0; tc < N0 && tc < C1; ++tc) {
             const double* p0 = fr.xs + sv_blk_index(r0, min(tc, r0)) + 2 * lane;
-            y0[tc] = sf64x4{ekf_ldc(p0), ekf_ldc(p0 + 1), ekf_ldc(p0 + 128), ekf_ldc(p0 + 129)};
+            if (!(has0 && i0 == NB)) z0[tc] = sf64x4{ekf_ldc(p0), ekf_ldc(p0 + 1), ekf_ldc(p0 + 128), ekf_ldc(p0 + 129)};
         }
 #pragma unroll
         for (int tc = C0; tc < N1 && tc < C1; ++tc) {
             const double* p0 = fr.xs + sv_blk_index(r1, min(tc, r1)) + 2 * lane;
-            y1[tc] = sf64x4{ekf_ldc(p0), ekf_ldc(p0 + 1), ekf_ldc(p0 + 128), ekf_ldc(p0 + 129)};
+            if (!(has1 && i1 == NB)) z1[tc] = sf64x4{ekf_ldc(p0), ekf_ldc(p0 + 1), ekf_ldc(p0 + 128), ekf_ldc(p0 + 129)};
         }
 #pragma unroll
         for (int tc = C0; tc < N0 && tc < C1; ++tc)
             if (blk0 && tc <= i0) {
-                z0[tc] = y0[tc];
                 settle_block(z0[tc], i0, tc, lane);
                 stale |= fr_tag_stale(t0[tc], fr.seqno);
             }
 #pragma unroll
         for (int tc = C0; tc < N1 && tc < C1; ++tc)
             if (blk1 && tc <= i1) {
-                z1[tc] = y1[tc];
                 settle_block(z1[tc], i1, tc, lane);
                 stale |= fr_tag_stale(t1[tc], fr.seqno);
             }
