@@ -41,10 +41,11 @@ struct Layout {
     int rd, lmd;      // rows per detection, landmark dims (model)
     int kmax;         // rd * max_visible rounded up to 16
     size_t elem;      // sizeof(cov element)
-    size_t off_jac, off_resid, off_y, off_lmcol, off_amat, off_sblk, off_lmat, off_dinv, off_lop, off_dop, off_wpanel, off_wpanel2, off_prow, off_wdbg,
+    size_t off_jac, off_resid, off_y, off_lmcol, off_amat, off_sblk, off_lmat, off_dinv, off_lop, off_dop, off_wpanel, off_wpanel2, off_cov2, off_wdbg,
         off_idx, off_z, off_status, off_stamps, off_dx, off_diag, off_xyz, off_unc,
         off_xl, off_done, off_sync, off_wsup, total;
-    int wsup_ld;      // row length of the compact support-column copy of W (pipelined sequence mode)
+    int wsup_ld;      // row length of the compact support-column copy of W (pipelined sequence mode; two copies, by frame parity)
+    bool has_cov2;
     // fused front kernel: one exchange buffer per fused-frame parity (offsets / length in doubles)
     size_t xl_len, xl_dop, xl_y, xl_jac, xl_tag, xl_xs, xl_xr, xl_stag;
 };
@@ -73,7 +74,11 @@ Layout make_layout(const ekf_config& c) {
     }
     L.off_wpanel = take((size_t)L.kmax * L.cap * L.elem);
     L.off_wpanel2 = take((size_t)L.kmax * L.cap * L.elem);
-    L.off_prow = take((size_t)(EKF_CAM + L.lmd * c.max_visible) * L.cap * L.elem);
+    // pipelined sequence mode (f32 covariance, MFMA update, fused front kernel): the second covariance buffer
+    // (P_t is read, P_{t+1} written elsewhere, so that the next front kernel can read P_t beside the update)
+    L.has_cov2 = c.cov_dtype == EKF_COV_F32 && c.cov_kernel != EKF_COVK_VALU && (c.flags & 5) == 0 &&
+                 ((c.flags & 2) != 0 || L.cap >= 2400);
+    L.off_cov2 = L.has_cov2 ? take((size_t)L.cap * L.cap * L.elem) : 0;
     L.off_wdbg = take((size_t)L.kmax * L.cap * 8);
     L.off_idx = take((size_t)c.max_visible * 4);
     L.off_z = take((size_t)c.max_visible * 7 * 8);
@@ -97,7 +102,7 @@ Layout make_layout(const ekf_config& c) {
         L.off_done = take(256);
         L.off_sync = take(256);
         L.wsup_ld = (int)round_up(EKF_CAM + (int64_t)L.lmd * c.max_visible, 32);
-        L.off_wsup = take((size_t)L.kmax * L.wsup_ld * L.elem);
+        L.off_wsup = take((size_t)2 * L.kmax * L.wsup_ld * L.elem);
     }
     L.total = o;
     return L;
@@ -574,14 +579,17 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
     if (!lm_index_dev || !z_dev) return fail(EKF_ERR_INVALID, "NULL detections");
     if (f->n_lm < 1) return fail(EKF_ERR_STATE, "observe before any landmark was added");
     // Pipelined mode (F(t+1) beside C(t), see below): flags bit 1 forces it, bit 0 forbids it, otherwise it is
-    // chosen where it was measured to win (tools/pipeline_sweep.py, f32 covariance, us per frame pipelined / serial:
-    // n=512 m=32 34.3 / 33.0 - n=1024 m=32 36.0 / 41.3 - n=2048 m=32 65.8 / 74.8 - n=2048 m=64 130.9 / 181.9 -
-    // n=4096 m=64 475 / 442; f64: the priority rows have no MFMA kernel, no gain)
+    // chosen where it was measured to win (tools/pipeline_sweep.py).  f32 covariance with the MFMA update and the
+    // fused front kernel only.
+    // (tools/pipeline_sweep.py, us per frame pipelined / serial: n=512 m=32 31.7 / 30.8 - n=1024 m=32 31.8 / 38.3 -
+    // n=1024 m=64 142.8 / 135.2 - n=2048 m=32 63.3 / 72.5 - n=2048 m=64 163.4 / 188.9 - n=4096 m=32 238.8 / 249.6 -
+    // n=4096 m=64 561.7 / 444.5)
     const int dims_now = f->dims();
-    const bool auto_on = f->cfg.cov_dtype == EKF_COV_F32 && f->cfg.cov_kernel != EKF_COVK_VALU && dims_now >= 2400 && dims_now <= 9000;
+    const int kpad_now = (int)round_up(f->lay.rd * m, EKF_RB);
+    const bool auto_on = kpad_now <= 96 ? dims_now >= 2400 : (dims_now >= 4800 && dims_now <= 9000);
     const bool want = (f->cfg.flags & 2) != 0 || ((f->cfg.flags & 1) == 0 && auto_on);
-    bool lookahead = want && !f->timing && frames >= 2 && (f->cfg.flags & 4) == 0;     // (fused front kernel only)
-    if (lookahead && f->la_ok < 0) {
+    bool pipelined = want && f->lay.has_cov2 && !f->timing && frames >= 2 && (f->cfg.flags & 4) == 0;
+    if (pipelined && f->la_ok < 0) {
         // The device-side gates need the two streams on DIFFERENT hardware queues (HIP maps streams to a small pool
         // of queues): a gate that shares its queue with the launch it waits for would wait for ever.  Probe once: a
         // gate on the internal stream, the matching signal on the handle's stream, a short poll budget.
@@ -597,8 +605,8 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
         HIP_TRY(hipMemcpy(&ps, pstat, 4, hipMemcpyDeviceToHost));
         f->la_ok = (ps == 0) ? 1 : 0;
     }
-    if (lookahead && f->la_ok == 0) lookahead = false;
-    if (!lookahead) {
+    if (pipelined && f->la_ok == 0) pipelined = false;
+    if (!pipelined) {
         for (int t = 0; t < frames; ++t) {
             rc = enqueue_frame(f, lm_index_dev + (size_t)t * m, z_dev + (size_t)t * m * f->lay.rd, m,
                                trajectory_dev ? trajectory_dev + (size_t)t * 7 : nullptr);
@@ -606,28 +614,34 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
         }
         return EKF_OK;
     }
-    // Pipelined sequence mode.  Stream A (the handle's): front kernel F(t), priority rows R(t) -- the rows of
-    // P_{t+1} that F(t+1) reads, so F(t+1) does not wait for the big update.  Stream B (internal): the covariance
-    // update C(t), which then runs BESIDE F(t+1).  Edges between the streams are ordered on the device:
-    //   R(t) complete  -> C(t) may start : F(t+1) stores "t+1 started" when it starts (it follows R(t) on stream
-    //                     A); a one-wave gate kernel in front of C(t) on stream B polls that counter;
-    //   C(t) complete  -> R(t+1) may read P : a one-thread kernel behind C(t) bumps a second counter; F(t+1) does
-    //                     not finish before it has seen it (its measurement workgroup polls at its end), and
-    //                     R(t+1) follows F(t+1) on stream A.
+    // Pipelined sequence mode.  One frame is a serial chain on one P, but the front kernel F(t+1) needs of P_{t+1}
+    // only its support rows (camera + the landmarks of frame t+1's detections), and those follow from P_t and W_t:
+    //     P_{t+1}[r][c] = (P_t[r][c] + Q[r == c]) + sum_k fma(-W_t[k][r], W_t[k][c])
+    // -- per element the instruction sequence of the covariance update, so the bits are the same.  The covariance
+    // therefore ping-pongs between two buffers: C(t) reads buf[t & 1] (P_t) and writes buf[(t + 1) & 1]; F(t+1) runs
+    // BESIDE C(t) on the other stream, reads P_t from buf[t & 1] and W_t, and completes the entries it needs itself
+    // (S-block workgroups: from the compact support columns W_sup the chunks of F(t) left behind; chunk workgroups:
+    // on the matrix cores).  Nothing on the critical path F(t) -> F(t+1) waits for a covariance update.
+    //   stream A (the handle's):  F(0) - F(1) - F(2) - ...
+    //   stream B (internal)    :  gate - C(0) - signal - gate - C(1) - signal ...
+    // Edges between the streams are ordered on the device (an event pair costs ~13 us per edge):
+    //   F(t) complete   -> C(t) may start (it reads W_t and overwrites the buffer F(t) read, P_{t-1}): F(t+1) stores
+    //                      "t+1 started" when it starts (it follows F(t) on stream A); a one-wave gate kernel in front
+    //                      of C(t) polls that counter (after the last frame a signal kernel stands in for F(t+1));
+    //   C(t-1) complete -> F(t+1) may read buf[t & 1] and overwrite W_{t-1}: a one-thread kernel behind C(t-1) bumps a
+    //                      second counter; F(t) does not finish before it has seen it (its measurement workgroup polls
+    //                      at its end), and F(t+1) follows F(t) on stream A.
     // Kernel boundaries on each stream give the memory ordering; the counters only carry "that launch is over".
-    // Every wait is bounded.  The front kernel claims (almost) all LDS of its CUs, so the covariance update's
-    // workgroups run on the other CUs instead of next to the pivot chain.
+    // Every wait is bounded.  The front kernel claims (almost) all LDS of its CUs while its grid is small, so the
+    // covariance update's workgroups run on the other CUs instead of next to the pivot chain.
     const Layout& L = f->lay;
-    const bool f32 = f->cfg.cov_dtype == EKF_COV_F32;
-    const int variant = f->cfg.cov_kernel == EKF_COVK_VALU ? 1 : 2;
     void* wbuf[2] = {f->at<void>(L.off_wpanel), f->at<void>(L.off_wpanel2)};
-    void* prow = f->at<void>(L.off_prow);
+    void* cbuf[2] = {f->cov, f->at<void>(L.off_cov2)};
+    char* wsup0 = f->at<char>(L.off_wsup);
+    void* wsup[2] = {wsup0, wsup0 + (size_t)L.kmax * L.wsup_ld * L.elem};
     unsigned long long* sync = f->at<unsigned long long>(L.off_sync);
     int32_t* status = f->at<int32_t>(L.off_status);
     const uint64_t base = f->la_base;
-    // The front kernel claims (almost) all LDS of its CUs while it has few workgroups (n=1024, m=32: 72 on 256
-    // CUs: 36.0 us per frame with the claim, 38.5 without); with a grid that approaches the CU count the claim only
-    // keeps the covariance update waiting (n=2048, m=32: 73.6 with, 65.8 without).
     static const char* la_env = getenv("EKF_LA_LDS_KB");          // (experiments)
     const int nb_now = (int)round_up(L.rd * m, EKF_RB) / EKF_RB;
     const int grid_now = nb_now * (nb_now + 1) / 2 + 2 + (int)round_up(f->dims(), 128) / 64;
@@ -640,38 +654,36 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
         EkfFrame fr = make_frame(f, lm_index_dev + (size_t)t * m, z_dev + (size_t)t * m * L.rd, m,
                                  trajectory_dev ? trajectory_dev + (size_t)t * 7 : nullptr);
         fr.wpanel = wbuf[par];
-        fr.prow = (t > 0) ? prow : nullptr;
+        if (t > 0) {                                           // P_{t-1} + the completion from W_{t-1}
+            fr.cov = cbuf[par ^ 1];
+            fr.wprev = wbuf[par ^ 1];
+            fr.wsup_prev = wsup[par ^ 1];
+        }
+        fr.wsup_ld = L.wsup_ld;
         fr.la_sync = sync;
-        fr.la_signal = (t > 0) ? base + (uint64_t)t : 0;       // "F(t) has started": R(t-1) is complete
+        fr.la_signal = (t > 0) ? base + (uint64_t)t : 0;       // "F(t) has started": F(t-1) is complete
         fr.la_gate = (t > 0) ? base + (uint64_t)t : 0;         // C(t-1) complete before F(t) ends
         fr.lds_min = la_lds;
-        if (t + 1 < frames) {                                  // the next frame's detections: support rows of R(t)
+        if (t + 1 < frames) {                                  // the next frame's detections: its support columns of W_t
             fr.next_idx = lm_index_dev + (size_t)(t + 1) * m;
             fr.next_m = m;
-            fr.wsup = f->at<void>(L.off_wsup);
-            fr.wsup_ld = L.wsup_ld;
+            fr.wsup = wsup[par];
         }
         bind_exchange(f, fr);
-        if (f32) ekf_launch_front<float>(fr, f->stream); else ekf_launch_front<double>(fr, f->stream);
-        if (t + 1 < frames) {
-            fr.prow_out = prow;
-            // (R(t) does not release C(t) itself although it could -- its last workgroup knows when P has been read: C(t)
-            // would then be dispatched BEFORE F(t+1), take every CU, and F(t+1), which wants CUs of its own, would start
-            // late: 37.2 us per frame instead of 34.6)
-            EkfFrame rr = fr;
-            rr.la_signal = 0;
-            rr.la_gate = 0;
-            if (f32) ekf_launch_cov_rows<float>(rr, f->stream); else ekf_launch_cov_rows<double>(rr, f->stream);
-        } else {
-            ekf_launch_signal(sync, base + (uint64_t)frames, f->stream);     // no F(t+1) to say that F(t) is over
-        }
+        ekf_launch_front<float>(fr, f->stream);
+        if (t + 1 == frames) ekf_launch_signal(sync, base + (uint64_t)frames, f->stream);     // no F(t+1) to say that F(t) is over
         ekf_launch_gate(sync, base + (uint64_t)t + 1, status, f->big);
-        if (f32) ekf_launch_cov_update<float>(fr, variant, f->big);
-        else ekf_launch_cov_update<double>(fr, variant, f->big);
+        EkfFrame cf = fr;
+        cf.cov = cbuf[par];
+        cf.cov_out = cbuf[par ^ 1];
+        ekf_launch_cov_update<float>(cf, 2, f->big);
         ekf_launch_signal(sync + 1, base + (uint64_t)t + 1, f->big);
         HIP_TRY(hipGetLastError());
     }
     f->la_base = base + (uint64_t)frames;
+    // an odd number of frames leaves the covariance in the internal buffer: back into the caller's
+    if (frames & 1)
+        HIP_TRY(hipMemcpyAsync(f->cov, cbuf[1], (size_t)L.cap * L.cap * L.elem, hipMemcpyDeviceToDevice, f->big));
     // join: everything later on the main stream (and every getter) sees the final covariance
     HIP_TRY(hipEventRecord(f->ev_big[0], f->big));
     HIP_TRY(hipStreamWaitEvent(f->stream, f->ev_big[0], 0));

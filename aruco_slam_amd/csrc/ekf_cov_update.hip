@@ -132,7 +132,10 @@ void ekf_cov_update_mfma_f32(EkfFrame fr, int nitems) {
     ekf_tri_decode(item, I, J);
     const int i0 = 32 * I, j0 = 32 * J;
     const float* __restrict__ wp = static_cast<const float*>(fr.wpanel);
-    float* __restrict__ P = static_cast<float*>(fr.cov);
+    // pipelined sequence mode: P_t is read from `cov` and P_{t+1} is written to `cov_out` (the next frame's front
+    // kernel reads P_t beside this launch); otherwise in place
+    const float* __restrict__ P = static_cast<const float*>(fr.cov);
+    float* Pout = fr.cov_out ? static_cast<float*>(fr.cov_out) : static_cast<float*>(fr.cov);
     const int ld = (int)fr.ld, ldw = (int)fr.ldw;
     constexpr int NCH = KB, D = (NCH < DMAX) ? NCH : DMAX;
     float ra[D][8], rb[D][8], pt[16];
@@ -145,7 +148,8 @@ void ekf_cov_update_mfma_f32(EkfFrame fr, int nitems) {
     const unsigned plane = 4u * (unsigned)(4 * lhi * ld + l31);     // C/D layout: row (reg&3) + 8 (reg>>2) + 4 lhi
     const uint64_t kstep = 8ull * (uint64_t)ldw;                    // two rows of W in bytes
     uint64_t ua = reinterpret_cast<uint64_t>(wp + i0), ub = reinterpret_cast<uint64_t>(wp + j0);
-    float* __restrict__ ptile = P + (int64_t)i0 * ld + j0;
+    const float* __restrict__ ptile = P + (int64_t)i0 * ld + j0;
+    float* otile = Pout + (int64_t)i0 * ld + j0;
 #define EKF_GLD(dst, voff, sbase) asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory")
 #define EKF_WAIT16(n, A, B)                                                                              \
     asm volatile("s_waitcnt vmcnt(%16)"                                                                   \
@@ -214,14 +218,14 @@ void ekf_cov_update_mfma_f32(EkfFrame fr, int nitems) {
         const int rl = (reg & 3) + 8 * (reg >> 2) + 4 * lhi;
         const float v = (pt[reg] + ((rl == l31) ? qlane : 0.0f)) + acc[reg];
         out[reg] = v;
-        stf(ptile + (int64_t)((reg & 3) + 8 * (reg >> 2)) * ld, plane, v);
+        stf(otile + (int64_t)((reg & 3) + 8 * (reg >> 2)) * ld, plane, v);
     }
     if (I != J) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg)
             tr[wave][(reg & 3) + 8 * (reg >> 2) + 4 * lhi][l31] = out[reg];
         __builtin_amdgcn_wave_barrier();
-        float* __restrict__ pm = P + (int64_t)j0 * ld + i0;
+        float* pm = Pout + (int64_t)j0 * ld + i0;
         const unsigned mlane = 4u * (unsigned)(lhi * ld + l31);
 #pragma unroll
         for (int it = 0; it < 16; ++it)          // column 2 it + lhi of D = row of D^T
@@ -358,156 +362,6 @@ __global__ __launch_bounds__(256) void ekf_cov_update_mfma_f64_split(EkfFrame fr
             ekf_cov_store(P + (int64_t)(j0 + cc) * ld + i0 + l31, tr[l31][cc]);
     }
 }
-
-// --------------------------------------------------------------------------
-// Priority rows (cross-frame lookahead): the rows of the UPDATED covariance that the next frame's
-// gather reads -- camera rows 0..9 and the 3 rows of every next-frame detection -- computed
-// ahead of the big kernel into a side buffer, with exactly the per-element arithmetic of the
-// kernels above (k-ordered fma chain from zero, then P + Q + acc): bitwise what the big kernel
-// then writes into P.  grid.x = 10 + 3 next_m rows, grid.y = column chunks.
-// --------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void ekf_cov_rows_kernel(EkfFrame fr) {
-    __shared__ T wr[192];                            // -W[:, row]
-    const int slot = blockIdx.x;
-    const int lmd = fr.model == 1 ? 10 : EKF_LM;     // state dims per landmark
-    int nidx = (slot < EKF_CAM) ? 0 : fr.next_idx[(slot - EKF_CAM) / lmd];
-    if ((unsigned)nidx >= (unsigned)fr.n_lm) nidx = 0;      // (reported by the next frame's kernels, which clamp the same way)
-    const int row = (slot < EKF_CAM) ? slot : EKF_CAM + lmd * nidx + (slot - EKF_CAM) % lmd;
-    const T* __restrict__ wp = static_cast<const T*>(fr.wpanel);
-    const T* __restrict__ P = static_cast<const T*>(fr.cov);
-    T* __restrict__ out = static_cast<T*>(fr.prow_out);
-    for (int kk = threadIdx.x; kk < fr.kpad; kk += 256) wr[kk] = -wp[(int64_t)kk * fr.ldw + row];
-    __syncthreads();
-    const T q = (T)ekf_qdiag(row, fr.dims, fr.nz);
-    for (int col = blockIdx.y * 256 + threadIdx.x; col < fr.ncols; col += gridDim.y * 256) {
-        T v = P[(int64_t)row * fr.ld + col];
-        T acc = (T)0;
-        for (int k0 = 0; k0 < fr.kpad; k0 += 16) {   // kpad is a multiple of 16: 16 loads in flight
-            T w[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) w[u] = wp[(int64_t)(k0 + u) * fr.ldw + col];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) acc = __builtin_fma(wr[k0 + u], w[u], acc);
-        }
-        if (row == col) v += q;
-        out[(int64_t)slot * fr.ldw + col] = v + acc;
-    }
-}
-
-// The same priority rows on the matrix cores (f32): one wave per 32 x 32 tile of the [slots x columns] block,
-// v_mfma_f32_32x32x2_f32 over k in ascending order with A = -W[:, row(slot)], B = W[:, column] and then
-// (P + Q) + acc -- per element the instruction sequence of ekf_cov_update_mfma_f32 (for an element above the
-// diagonal the big kernel runs the mirrored product, the same bits), so the rows are bitwise what the big kernel
-// writes.  The A operand comes from W_sup, the compact copy of the support columns that the front kernel's chunks
-// leave behind (a first version gathered W[k][row(slot)] per tile: 32 cache lines per load instruction, 16 us;
-// the VALU version above: 11.7 us at n=1024, m=32).
-template <int KB>
-__global__ __launch_bounds__(256) void ekf_cov_rows_mfma_f32(EkfFrame fr, int nslots) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, lhi = lane >> 5;
-    const int lmd = fr.model == 1 ? 10 : EKF_LM;
-    const int tile_i = blockIdx.y * 4 + wave;                 // 32 slots
-    const int j0 = 32 * blockIdx.x;
-    const float* __restrict__ wp = static_cast<const float*>(fr.wpanel);
-    const float* __restrict__ ws = static_cast<const float*>(fr.wsup);
-    const float* __restrict__ P = static_cast<const float*>(fr.cov);
-    float* __restrict__ out = static_cast<float*>(fr.prow_out);
-    const int64_t ld = fr.ld, ldw = fr.ldw, lds = fr.wsup_ld;
-    const float* wa = ws + (int64_t)lhi * lds + 32 * tile_i + l31;      // A operand: lane (i = l31, k = lhi)
-    const float* wb = wp + (int64_t)lhi * ldw + j0 + l31;               // B operand: lane (k = lhi, j = l31)
-    // operand ring, D chunks of 8 k-pairs in flight (a wave per tile and ~1.5 waves per CU: nothing else hides
-    // the ~1 us of an L2 / Infinity-Cache round trip, and a chunk-by-chunk loop is 12 of them in a row).  These
-    // loads do not depend on the next frame's indices: they go out before the slot -> row map is built.
-    constexpr int D = KB < 4 ? KB : 4;
-    float ra[D][8], rb[D][8];
-    const bool tile_ok = 32 * tile_i < nslots;
-    if (tile_ok) {
-#pragma unroll
-        for (int c = 0; c < D; ++c)
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                ra[c][u] = wa[(int64_t)(2 * (8 * c + u)) * lds];
-                rb[c][u] = wb[(int64_t)(2 * (8 * c + u)) * ldw];
-            }
-    }
-    // slot -> row of P, once per workgroup (ONE round trip for the next frame's indices; computing it per
-    // register made hipcc wait for 16 index loads one after the other: 15 us for this kernel)
-    __shared__ int rowmap[128];
-    if (threadIdx.x < 128) {
-        const int slot = 128 * blockIdx.y + threadIdx.x;
-        const int jn = min(max((slot - EKF_CAM) / lmd, 0), fr.next_m - 1);
-        int nidx = fr.next_idx[jn];
-        if ((unsigned)nidx >= (unsigned)fr.n_lm) nidx = 0;
-        const int lrow = EKF_CAM + lmd * nidx + (slot - EKF_CAM) % lmd;
-        rowmap[threadIdx.x] = (slot < EKF_CAM) ? slot : (slot < nslots ? lrow : 0);
-    }
-    __syncthreads();
-    auto row_of = [&](int slot) { return rowmap[slot - 128 * blockIdx.y]; };
-    if (tile_ok) {
-    // C / D layout: register reg <-> tile row (reg & 3) + 8 (reg >> 2) + 4 lhi, column l31
-    float pt[16];
-    int prow_of[16];
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        prow_of[reg] = row_of(32 * tile_i + (reg & 3) + 8 * (reg >> 2) + 4 * lhi);
-        pt[reg] = P[(int64_t)prow_of[reg] * ld + j0 + l31];
-    }
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-    for (int c = 0; c < KB; ++c) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-ra[c % D][u], rb[c % D][u], acc, 0, 0, 0);
-        if (c + D < KB) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                ra[c % D][u] = wa[(int64_t)(2 * (8 * (c + D) + u)) * lds];
-                rb[c % D][u] = wb[(int64_t)(2 * (8 * (c + D) + u)) * ldw];
-            }
-        }
-    }
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int slot = 32 * tile_i + (reg & 3) + 8 * (reg >> 2) + 4 * lhi;
-        const float q = (prow_of[reg] == j0 + l31) ? (float)ekf_qdiag(prow_of[reg], fr.dims, fr.nz) : 0.0f;
-        if (slot < nslots) ekf_cov_store(out + (int64_t)slot * ldw + j0 + l31, (pt[reg] + q) + acc[reg]);
-    }
-    }
-    // pipelined sequence mode: once EVERY workgroup has read its rows of P, the covariance update (other stream) may
-    // overwrite P -- the last workgroup to get here says so (the next front kernel says it again when it starts)
-    if (fr.la_signal) {
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned long long old = __hip_atomic_fetch_add(fr.la_sync + 4, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old + 1 == fr.la_gate)       // (la_gate: cumulative number of workgroups of all priority-row launches so far)
-                __hip_atomic_store(fr.la_sync, fr.la_signal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-}
-
-template <typename T>
-void ekf_launch_cov_rows(const EkfFrame& fr, hipStream_t s) {
-    const int chunks = (fr.ncols + 255) / 256;      // one column per thread
-    hipLaunchKernelGGL(ekf_cov_rows_kernel<T>, dim3(EKF_CAM + (fr.model == 1 ? 10 : EKF_LM) * fr.next_m, chunks), dim3(256), 0, s, fr);
-}
-template <>
-void ekf_launch_cov_rows<float>(const EkfFrame& fr, hipStream_t s) {
-    const int nslots = EKF_CAM + (fr.model == 1 ? 10 : EKF_LM) * fr.next_m;
-    if (!fr.wsup) {     // no compact support columns (stage kernels): the VALU version gathers for itself
-        hipLaunchKernelGGL(ekf_cov_rows_kernel<float>, dim3(nslots, (fr.ncols + 255) / 256), dim3(256), 0, s, fr);
-        return;
-    }
-    const dim3 grid(fr.ncols / 32, (nslots + 127) / 128), block(256);
-    switch (fr.kpad / 16) {
-#define EKF_ROWS_CASE(KB) case KB: hipLaunchKernelGGL(ekf_cov_rows_mfma_f32<KB>, grid, block, 0, s, fr, nslots); break;
-        EKF_ROWS_CASE(1) EKF_ROWS_CASE(2) EKF_ROWS_CASE(3) EKF_ROWS_CASE(4) EKF_ROWS_CASE(5) EKF_ROWS_CASE(6)
-        EKF_ROWS_CASE(7) EKF_ROWS_CASE(8) EKF_ROWS_CASE(9) EKF_ROWS_CASE(10) EKF_ROWS_CASE(11)
-        default: hipLaunchKernelGGL(ekf_cov_rows_mfma_f32<12>, grid, block, 0, s, fr, nslots); break;
-#undef EKF_ROWS_CASE
-    }
-}
-template void ekf_launch_cov_rows<double>(const EkfFrame&, hipStream_t);
 
 // Pipelined sequence mode: ordering between the two streams on the device (an event pair costs ~13 us per edge,
 // stream write / wait values ~7 us, a resident one-wave kernel that polls a counter ~1.2 us:

@@ -42,6 +42,11 @@
 
 #define FR_T 512
 #define FR_ALD 66          // row stride (doubles) of the A chunk in LDS
+// doubles of the chunk role's A region (pipelined mode: at least the 128 x 64 f32 support-row tiles of one round)
+__host__ __device__ inline size_t fr_chunk_a_len(int kpad, bool fix) {
+    const size_t a = (size_t)kpad * FR_ALD;
+    return (fix && a < 4096) ? 4096 : a;
+}
 
 typedef double pf64x4 __attribute__((ext_vector_type(4)));
 
@@ -93,19 +98,43 @@ __device__ __forceinline__ void fr_role_sblock(const EkfFrame& fr, int sb, int n
     double* rsd = us + NSLOT * 16 + 32;                 // [kpad] z - h (workgroup 0 only)
     const int tid = threadIdx.x, m = fr.m, k = fr.k;
     const T* __restrict__ P = static_cast<const T*>(fr.cov);
-    const T* __restrict__ prow = static_cast<const T*>(fr.prow);
     const int64_t ld = fr.ld;
     double cam[EKF_CAM];
 #pragma unroll
     for (int a = 0; a < EKF_CAM; ++a) cam[a] = fr.state[a];
     if (fr.stamps && sb == 0 && tid == 0) fr.stamps[60] = wall_clock64();
+    int bi = 0, bj = sb;
+    while (bj > bi) { bj -= bi + 1; ++bi; }
+    const int j0 = (16 * bi) / RD, jc0 = (16 * bj) / RD;
+    // Pipelined sequence mode: `cov` is P of the PREVIOUS frame (the covariance update that produces the current P
+    // runs beside this launch).  The entries this block needs are completed on the fly,
+    //     P_cur[r][c] = (P_prev[r][c] + Q[r == c]) + sum_k fma(-W[k][r], W[k][c]),     k ascending from zero,
+    // the per-element instruction sequence of the covariance update (ekf_cov_update.hip): the same bits.  Both r and
+    // c are support rows of this frame, so the W columns come from the compact copy W_sup[k][slot] that the previous
+    // front kernel left behind: row slots {0..9} + [10 + LMD j0, ..), column slots {0..9} + [10 + LMD jc0, ..).
+    // The loads do not depend on the indices: they are in flight during the index -> P round trips.
+    const bool fix = sizeof(T) == 4 && fr.wsup_prev != nullptr;
+    float* wr = reinterpret_cast<float*>(rsd + fr.kpad);      // [kpad][NSLOT]  -W_sup[:, row slots]
+    float* wc = wr + fr.kpad * NSLOT;                         // [kpad][NSLOT]   W_sup[:, column slots]
+    float* dots = wc + fr.kpad * NSLOT;                       // [NSLOT][NSLOT]
+    constexpr int NWL = (192 * NSLOT + FR_T - 1) / FR_T;
+    float wrv[NWL], wcv[NWL];
+    if (fix) {
+        const float* __restrict__ wsp = static_cast<const float*>(fr.wsup_prev);
+        const int smax = fr.wsup_ld - 1;
+#pragma unroll
+        for (int n = 0; n < NWL; ++n) {
+            const int e = min(tid + FR_T * n, fr.kpad * NSLOT - 1), kk = e / NSLOT, sl = e % NSLOT;
+            const int gr = (sl < EKF_CAM) ? sl : min(EKF_CAM + LMD * j0 + (sl - EKF_CAM), smax);
+            const int gc = (sl < EKF_CAM) ? sl : min(EKF_CAM + LMD * jc0 + (sl - EKF_CAM), smax);
+            wrv[n] = wsp[(int64_t)kk * fr.wsup_ld + gr];
+            wcv[n] = wsp[(int64_t)kk * fr.wsup_ld + gc];
+        }
+    }
     if (tid < m) lmc[tid] = ekf_lm_column(fr, LMD, tid, false);
     __syncthreads();
     // this thread's entry of U (slot, c2): its P values are requested before the measurement model
     // is evaluated, so the two dependent memory round trips overlap
-    int bi = 0, bj = sb;
-    while (bj > bi) { bj -= bi + 1; ++bi; }
-    const int j0 = (16 * bi) / RD;
     constexpr int NE = (NSLOT * 16 + FR_T - 1) / FR_T;  // entries of U per thread (1 or 2)
     int urho[NE], uc20[NE], ur2[NE];
     bool uact[NE];
@@ -121,8 +150,7 @@ __device__ __forceinline__ void fr_role_sblock(const EkfFrame& fr, int sb, int n
         uc20[n] = 0;
         if (uact[n]) {
             urho[n] = (uslot < EKF_CAM) ? uslot : lmc[uj] + ud;
-            const T* prw = prow ? prow + (int64_t)((uslot < EKF_CAM) ? uslot : EKF_CAM + LMD * uj + ud) * fr.ldw
-                                : P + (int64_t)urho[n] * ld;
+            const T* prw = P + (int64_t)urho[n] * ld;
             uc20[n] = lmc[ur2[n] / RD];
 #pragma unroll
             for (int b = 0; b < EKF_CAM; ++b) pv[n][b] = prw[b];
@@ -130,8 +158,52 @@ __device__ __forceinline__ void fr_role_sblock(const EkfFrame& fr, int sb, int n
             for (int b = 0; b < LMD; ++b) pv[n][EKF_CAM + b] = prw[uc20[n] + b];
         }
     }
+    if (fix) {
+#pragma unroll
+        for (int n = 0; n < NWL; ++n) {
+            const int e = tid + FR_T * n;
+            if (e < fr.kpad * NSLOT) {
+                wr[e] = -wrv[n];
+                wc[e] = wcv[n];
+            }
+        }
+    }
     fr_measure<MODEL>(fr, cam, lmc, hs, rsd, tid, false);
     __syncthreads();
+    if (fix) {
+        constexpr int NDT = (NSLOT * NSLOT + FR_T - 1) / FR_T;
+        float dacc[NDT];
+        int drs[NDT], dcs[NDT];
+#pragma unroll
+        for (int n = 0; n < NDT; ++n) {
+            const int e = min(tid + FR_T * n, NSLOT * NSLOT - 1);
+            drs[n] = e / NSLOT;
+            dcs[n] = e % NSLOT;
+            dacc[n] = 0.0f;
+        }
+        for (int kk = 0; kk < fr.kpad; ++kk) {
+#pragma unroll
+            for (int n = 0; n < NDT; ++n) dacc[n] = __builtin_fmaf(wr[kk * NSLOT + drs[n]], wc[kk * NSLOT + dcs[n]], dacc[n]);
+        }
+#pragma unroll
+        for (int n = 0; n < NDT; ++n)
+            if (tid + FR_T * n < NSLOT * NSLOT) dots[tid + FR_T * n] = dacc[n];
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < NE; ++n) {
+            if (uact[n]) {
+                const int uslot = (tid + FR_T * n) >> 4;
+                const int cdet = EKF_CAM + LMD * (ur2[n] / RD - jc0);
+#pragma unroll
+                for (int b = 0; b < JC; ++b) {
+                    const int col = (b < EKF_CAM) ? b : uc20[n] + (b - EKF_CAM);
+                    const int cs = (b < EKF_CAM) ? b : cdet + (b - EKF_CAM);
+                    const float q = (col == urho[n]) ? (float)ekf_qdiag(urho[n], fr.dims, fr.nz) : 0.0f;
+                    pv[n][b] = (T)(((float)pv[n][b] + q) + dots[uslot * NSLOT + cs]);
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int n = 0; n < NE; ++n) {
         const int ue = tid + FR_T * n;
@@ -569,35 +641,122 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
     if (stp) stp[NB] = wall_clock64();
 }
 
+// Pipelined sequence mode: one 32 x 32 tile of the CURRENT covariance's support rows, [32 slots] x [32 columns of this
+// chunk], from the previous frame's P and W (see fr_role_sblock):  (P_prev + Q) + sum_k fma(-W_sup[k][slot], W[k][col]),
+// v_mfma_f32_32x32x2_f32 over k in ascending order -- per element the instruction sequence of ekf_cov_update_mfma_f32
+// (for an element above the diagonal that kernel runs the mirrored product: the same bits).  One wave; the result goes
+// to `pl` ([128 slots of this round][64 columns], f32) in LDS.  A operand: lane (i = l31, k = lhi) from W_sup; B operand:
+// lane (k = lhi, j = l31) from the W panel; ring of D chunks of 8 k-pairs in flight.
+typedef float fr_f32x16 __attribute__((ext_vector_type(16)));
+template <int NB, int MODEL>
+__device__ __forceinline__ void fr_rows_tile(const EkfFrame& fr, const int* lmc, float* pl, int tile_i, int tile_l, int j0, int jl,
+                                             int lane, int nslots) {
+    constexpr int LMD = EkfModel<MODEL>::LMD, KB = NB, D = KB < 4 ? KB : 4;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const float* __restrict__ P = static_cast<const float*>(fr.cov);
+    const int64_t ld = fr.ld, ldw = fr.ldw, lds = fr.wsup_ld;
+    const float* wa = static_cast<const float*>(fr.wsup_prev) + (int64_t)lhi * lds + 32 * tile_i + l31;
+    const float* wb = static_cast<const float*>(fr.wprev) + (int64_t)lhi * ldw + j0 + l31;
+    float ra[D][8], rb[D][8];
+#pragma unroll
+    for (int c = 0; c < D; ++c)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            ra[c][u] = wa[(int64_t)(2 * (8 * c + u)) * lds];
+            rb[c][u] = wb[(int64_t)(2 * (8 * c + u)) * ldw];
+        }
+    // C / D layout: register reg <-> tile row (reg & 3) + 8 (reg >> 2) + 4 lhi, column l31
+    float pt[16];
+    int prow_of[16];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int slot = 32 * tile_i + (reg & 3) + 8 * (reg >> 2) + 4 * lhi;
+        const int sj = min(max((slot - EKF_CAM) / LMD, 0), fr.m - 1);
+        prow_of[reg] = (slot < EKF_CAM) ? slot : (slot < nslots ? lmc[sj] + (slot - EKF_CAM) % LMD : 0);
+        pt[reg] = P[(int64_t)prow_of[reg] * ld + j0 + l31];
+    }
+    fr_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < KB; ++c) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-ra[c % D][u], rb[c % D][u], acc, 0, 0, 0);
+        if (c + D < KB) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                ra[c % D][u] = wa[(int64_t)(2 * (8 * (c + D) + u)) * lds];
+                rb[c % D][u] = wb[(int64_t)(2 * (8 * (c + D) + u)) * ldw];
+            }
+        }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int rl = (reg & 3) + 8 * (reg >> 2) + 4 * lhi;
+        const float q = (prow_of[reg] == j0 + l31) ? (float)ekf_qdiag(prow_of[reg], fr.dims, fr.nz) : 0.0f;
+        pl[(32 * tile_l + rl) * 64 + jl + l31] = (pt[reg] + q) + acc[reg];
+    }
+}
+
 template <typename T, int NU, int MODEL, int NB>
 __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, double* sm) {
     constexpr int RD = EkfModel<MODEL>::RD, LMD = EkfModel<MODEL>::LMD, JC = EkfModel<MODEL>::JC;
     constexpr int NWV = FR_T / 64;
     double* hs = sm;                                    // [k][JC]
-    double* a_lds = sm + fr.k * JC;                     // [kpad][FR_ALD]
-    int* lmc = reinterpret_cast<int*>(a_lds + (size_t)fr.kpad * FR_ALD);
+    double* a_lds = sm + fr.k * JC;                     // [kpad][FR_ALD]; before A is built: the support-row tiles (pipelined mode)
+    const bool fix = sizeof(T) == 4 && fr.wprev != nullptr;
+    const size_t a_len = fr_chunk_a_len(fr.kpad, fix);
+    int* lmc = reinterpret_cast<int*>(a_lds + a_len);
     int* flag = lmc + 64;                               // [0] last-chunk flag, [1..2] panel sync words
     double* pshare = reinterpret_cast<double*>(lmc + 72);   // [8][64] Dinv operands and y of one block column
     const int tid = threadIdx.x, m = fr.m;
     const int chunk0 = chunk * 64, cl = tid & 63, c = chunk0 + cl, g = tid >> 6;
     const T* __restrict__ P = static_cast<const T*>(fr.cov);
-    const T* __restrict__ prow = static_cast<const T*>(fr.prow);
     const int64_t ld = fr.ld;
     if (fr.stamps && chunk == 0 && tid == 0) fr.stamps[32] = wall_clock64();
     T pcr[EKF_CAM];
+    T plr[NU][LMD];
+    if (!fix) {
 #pragma unroll
-    for (int a = 0; a < EKF_CAM; ++a) pcr[a] = prow ? prow[(int64_t)a * fr.ldw + c] : P[a * ld + c];
+        for (int a = 0; a < EKF_CAM; ++a) pcr[a] = P[a * ld + c];
+    }
     if (tid < m) lmc[tid] = ekf_lm_column(fr, LMD, tid, false);
     if (tid == 0) { flag[1] = 0; flag[2] = 0; }
     __syncthreads();
-    T plr[NU][LMD];
+    if (!fix) {
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        const int ju = min(g + NWV * u, m - 1);
-        const int c0 = lmc[ju];
+        for (int u = 0; u < NU; ++u) {
+            const int ju = min(g + NWV * u, m - 1);
+            const int c0 = lmc[ju];
 #pragma unroll
-        for (int d = 0; d < LMD; ++d)
-            plr[u][d] = prow ? prow[(int64_t)(EKF_CAM + LMD * ju + d) * fr.ldw + c] : P[(int64_t)(c0 + d) * ld + c];
+            for (int d = 0; d < LMD; ++d) plr[u][d] = P[(int64_t)(c0 + d) * ld + c];
+        }
+    } else if constexpr (sizeof(T) == 4) {
+        // Pipelined sequence mode: `cov` is the PREVIOUS frame's P; the support rows of the current one (10 + LMD m
+        // slots x this chunk's 64 columns) are completed on the matrix cores, 128 slots per round: 8 tiles, one per
+        // wave, through LDS (the region that becomes the A chunk afterwards), from where every thread takes the rows
+        // of its detections.
+        float* pl = reinterpret_cast<float*>(a_lds);
+        const int nslots = EKF_CAM + LMD * m;
+        for (int round = 0; 128 * round < nslots; ++round) {
+            const int tile_l = g >> 1, tile_i = 4 * round + tile_l, jl = 32 * (g & 1);
+            if (32 * tile_i < nslots) fr_rows_tile<NB, MODEL>(fr, lmc, pl, tile_i, tile_l, chunk0 + jl, jl, tid & 63, nslots);
+            __syncthreads();
+            if (round == 0) {
+#pragma unroll
+                for (int a = 0; a < EKF_CAM; ++a) pcr[a] = (T)pl[a * 64 + cl];
+            }
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int ju = min(g + NWV * u, m - 1);
+#pragma unroll
+                for (int d = 0; d < LMD; ++d) {
+                    const int slot = EKF_CAM + LMD * ju + d;
+                    if ((slot >> 7) == round) plr[u][d] = (T)pl[(slot & 127) * 64 + cl];
+                }
+            }
+            __syncthreads();
+        }
     }
     // Jacobian rows: published by S-block workgroup 0 (this role never reads the state, so the
     // injection at the end of the launch cannot race with a chunk that starts late)
@@ -724,8 +883,10 @@ static void ekf_front_go(const EkfFrame& fr, hipStream_t s) {
         once = true;
     }
     const int nb = fr.kpad / EKF_RB, nS = nb * (nb + 1) / 2;
-    const size_t lds_s = ((size_t)fr.k * JC + NSLOT * 16 + 32 + fr.kpad) * 8 + 16;
-    const size_t lds_c = ((size_t)fr.k * JC + (size_t)fr.kpad * FR_ALD) * 8 + 72 * 4 + 8 * 64 * 8 + 16;
+    const bool fix = sizeof(T) == 4 && fr.wprev != nullptr;
+    const size_t lds_s = ((size_t)fr.k * JC + NSLOT * 16 + 32 + fr.kpad) * 8 + 16 +
+                         (fix ? ((size_t)2 * fr.kpad * NSLOT + NSLOT * NSLOT) * 4 : 0);
+    const size_t lds_c = ((size_t)fr.k * JC + fr_chunk_a_len(fr.kpad, fix)) * 8 + 72 * 4 + 8 * 64 * 8 + 16;
     const size_t lds_f = (size_t)sv_lds_doubles(NB) * 8;
     size_t lds = lds_s > lds_c ? lds_s : lds_c;
     if (lds_f > lds) lds = lds_f;

@@ -51,14 +51,19 @@ struct EkfFrame {
     double* traj_row;      // optional: state[0:7] after the update
     double* dxvec;         // model 1: dx = W^T y for every state dimension (input of the injection kernel)
     long long* stamps;     // optional: s_memtime stamps of the solve kernel's phases (diagnostics)
-    // cross-frame lookahead (sequence mode).  After the panel kernel of frame t, ekf_launch_cov_rows
-    // computes the rows of P_{t+1} that frame t+1's gather will read (camera rows 0..9 and the 3
-    // rows of every detection of frame t+1) into prow_out [10 + 3 next_m, ldw]; the gather of
-    // frame t+1 reads them from `prow` instead of P, so it no longer waits for the big update.
-    const int32_t* next_idx;   // [next_m] landmark indices of the next frame (device)
+    // Pipelined sequence mode (ekf_api.hip: ekf_observe_sequence_device).  The covariance lives in TWO buffers: the
+    // update of frame t reads `cov` (P_t) and writes `cov_out` (P_{t+1}); the front kernel of frame t+1 runs beside it
+    // and takes the entries of P_{t+1} it needs -- support rows only -- from P_t and W_t on the fly:
+    //     P_{t+1}[r][c] = (P_t[r][c] + Q[r == c]) + sum_k fma(-W_t[k][r], W_t[k][c])     (k ascending, from zero)
+    // which is, instruction for instruction, what the covariance update computes for that element (bitwise equal).
+    // For such a front kernel `cov` is P_t (the PREVIOUS frame's input), `wprev` the previous frame's W panel and
+    // `wsup_prev` the compact copy of its support columns, W_t[:, row(slot)], slot = 10 + lmd j + d for detection
+    // j of THIS frame (written by the previous front kernel's chunks, which know this frame's indices: next_idx).
+    const int32_t* next_idx;   // [next_m] landmark indices of the next frame (device); null: none
     int32_t next_m;
-    void* prow_out;            // written by ekf_launch_cov_rows (cov dtype)
-    const void* prow;          // read by the gather kernel; null = read P
+    void* cov_out;             // covariance update: destination (null = in place)
+    const void* wprev;         // front kernel: W panel of the previous frame [kpad][ldw] (null = `cov` is current)
+    const void* wsup_prev;     // front kernel: [kpad][wsup_ld], see above
     // device-side cross-stream ordering of the pipelined sequence mode (ekf_api.hip: run_pipelined):
     // la_sync[0] = "front kernel of frame n has started" counter, la_sync[1] = "covariance update of frame n is
     // complete" counter.  A front kernel stores la_signal into [0] when it starts (0 = no) and does not
@@ -66,7 +71,7 @@ struct EkfFrame {
     unsigned long long* la_sync;
     unsigned long long la_signal, la_gate;
     int32_t lds_min;           // front kernel: claim at least this much LDS (keeps other kernels' workgroups off its CUs)
-    void* wsup;                // pipelined mode: W[:, support rows of the next frame], [kpad][wsup_ld] in cov dtype (null: none)
+    void* wsup;                // pipelined mode, written by the chunks: W[:, support rows of the NEXT frame], [kpad][wsup_ld] in cov dtype (null: none)
     int32_t wsup_ld;
     EkfNoise nz;
     int32_t quat_mode;
@@ -113,7 +118,6 @@ template <typename T> void ekf_launch_panel(const EkfFrame& fr, hipStream_t s);
 // e0 / e1 (optional): events that receive the kernel's own start / stop time stamps (hipExtLaunchKernelGGL)
 template <typename T> void ekf_launch_cov_update(const EkfFrame& fr, int variant, hipStream_t s,
                                                  hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
-template <typename T> void ekf_launch_cov_rows(const EkfFrame& fr, hipStream_t s);
 // pipelined sequence mode: one-wave kernels that order the two streams on the device
 void ekf_launch_gate(unsigned long long* counter, unsigned long long target, int32_t* status, hipStream_t s,
                      int max_polls = 1 << 22);

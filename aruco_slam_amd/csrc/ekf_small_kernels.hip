@@ -43,13 +43,10 @@ __global__ __launch_bounds__(256) void ekf_gather_kernel(EkfFrame fr) {
     const int g = tid >> 6;                        // wave index: wave-uniform landmark
     const T* __restrict__ P = static_cast<const T*>(fr.cov);
     const int64_t ld = fr.ld;
-    // support rows come from P, or -- cross-frame lookahead -- from the priority-row buffer that
-    // ekf_cov_rows_kernel filled with exactly the values the covariance update is writing into P
-    const T* __restrict__ prow = static_cast<const T*>(fr.prow);
     // camera rows of P for this column and the camera state: independent of idx
     T pcr[EKF_CAM];
 #pragma unroll
-    for (int a = 0; a < EKF_CAM; ++a) pcr[a] = prow ? prow[(int64_t)a * fr.ldw + c] : P[a * ld + c];
+    for (int a = 0; a < EKF_CAM; ++a) pcr[a] = P[a * ld + c];
     double cam[EKF_CAM];
 #pragma unroll
     for (int a = 0; a < EKF_CAM; ++a) cam[a] = fr.state[a];
@@ -63,7 +60,7 @@ __global__ __launch_bounds__(256) void ekf_gather_kernel(EkfFrame fr) {
         const int c0 = lmc[ju];
 #pragma unroll
         for (int d = 0; d < LMD; ++d)
-            plr[u][d] = prow ? prow[(int64_t)(EKF_CAM + LMD * ju + d) * fr.ldw + c] : P[(int64_t)(c0 + d) * ld + c];
+            plr[u][d] = P[(int64_t)(c0 + d) * ld + c];
     }
     if (tid < m) {
         const int c0 = lmc[tid];
@@ -96,8 +93,7 @@ __global__ __launch_bounds__(256) void ekf_gather_kernel(EkfFrame fr) {
             double acc = 0.0;
             if (r2 < k && (slot < EKF_CAM || j < m)) {
                 const int rho = (slot < EKF_CAM) ? slot : lmc[j] + d;
-                const T* prw = prow ? prow + (int64_t)((slot < EKF_CAM) ? slot : EKF_CAM + LMD * j + d) * fr.ldw
-                                    : P + (int64_t)rho * ld;
+                const T* prw = P + (int64_t)rho * ld;
                 const double* h2 = hs + r2 * JC;
                 const int c20 = lmc[r2 / RD];
                 T pv[JC];

@@ -272,8 +272,9 @@ def main():
                                f"{args.cov_dtype} covariance, one independent sequence per GPU",
                    "sequences": world, "cov_kernel": args.cov_kernel,
                    "front": "stage kernels" if args.unfused else "fused front kernel",
-                   "sequence_mode": {"auto": "pipelined where it wins (f32 covariance, 2400 <= N <= 9000: front kernel of "
-                                             "frame t+1 beside the covariance update of frame t), else serial",
+                   "sequence_mode": {"auto": "pipelined where it wins (f32 covariance, N >= 2400 at k <= 96, 4800 <= N <= 9000 above: "
+                                             "front kernel of frame t+1 beside the covariance update of frame t, "
+                                             "covariance ping-pong between two buffers), else serial",
                                      "on": "pipelined", "off": "serial"}[args.lookahead]},
         "roofline": dict(rl_primary, **{
                      "kernel": "ekf_cov_update (P <- P + Q - W^T W)",

@@ -67,7 +67,9 @@ typedef struct ekf_config {
     int32_t reserved;
     int32_t flags;          /* bits 0-1: pipelined mode of ekf_observe_sequence_device (the front kernel of frame t+1 runs
                              * beside the covariance update of frame t; same results, bit for bit): 0 = chosen by size
-                             * (on for an f32 covariance of 2400..9000 state dimensions), bit 0 = never, bit 1 = always.
+                             * (f32 covariance with the MFMA update only; on from 2400 state dimensions for up to 32
+                             * detections per frame, 4800..9000 above), bit 0 = never, bit 1 = always.  Unless bit 0
+                             * is set, a capable configuration adds a second covariance buffer to the workspace.
                              * bit 2: run gather / solve / panel as three separate launches instead of the fused front
                              * kernel (same results, bit for bit; no pipelined mode).  bit 3 is ignored. */
     /* noise constants, defaults = extended_kalman_filter.py:21-27 */
@@ -128,13 +130,14 @@ int ekf_observe_device(ekf_filter *f, const int32_t *lm_index_dev,
 /* `frames` consecutive observe() calls on device-resident detections
  * lm_index_dev [frames,m], z_dev [frames,m,3]; after every frame the camera
  * pose state[0:7] is appended to trajectory_dev [frames,7] (may be NULL).
- * Because the next frame's detections are known, the rows of the updated
- * covariance that frame t+1 reads can be produced first by a small kernel, and the
- * big covariance update of frame t then runs on an internal second stream beside
- * frame t+1's front kernel (pipelined mode, see ekf_config.flags; the two streams are ordered
- * by one-wave gate kernels on the device, every wait bounded; same arithmetic per element:
- * results are bitwise those of per-frame ekf_observe calls).  The call returns with the
- * handle's stream waiting for the internal one. */
+ * Pipelined mode (see ekf_config.flags): the covariance update of frame t runs on an internal
+ * second stream BESIDE frame t+1's front kernel.  The covariance ping-pongs between the caller's
+ * buffer and a second one in the workspace (the update reads P_t and writes P_{t+1} elsewhere), and
+ * the front kernel of frame t+1 completes the few rows of P_{t+1} it reads from P_t and W_t on the
+ * fly, with the update's own per-element instruction sequence: results are bitwise those of
+ * per-frame ekf_observe calls.  The two streams are ordered by one-wave gate kernels on the
+ * device, every wait bounded.  The call returns with the handle's stream waiting for the internal
+ * one and the covariance back in the caller's buffer. */
 int ekf_observe_sequence_device(ekf_filter *f, const int32_t *lm_index_dev,
                                 const double *z_dev, int32_t m, int32_t frames,
                                 double *trajectory_dev);
