@@ -645,6 +645,10 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
     static const char* la_env = getenv("EKF_LA_LDS_KB");          // (experiments)
     const int nb_now = (int)round_up(L.rd * m, EKF_RB) / EKF_RB;
     const int grid_now = nb_now * (nb_now + 1) / 2 + 2 + (int)round_up(f->dims(), 128) / 64;
+    static const char* wpe_env = getenv("EKF_PIPE_WPE");          // (experiments) occupancy of the update beside the front kernel
+    const int pipe_variant = wpe_env ? 10 + atoi(wpe_env) : 2;
+    static const char* late_env = getenv("EKF_LA_LATE");          // (experiments)
+    const int la_late = late_env ? atoi(late_env) : 0;
     const int la_lds = la_env ? atoi(la_env) * 1024 : (grid_now <= 100 ? 148 * 1024 : 0);
     // stream B starts from everything that is on stream A now (the previous call ended with the reverse join)
     HIP_TRY(hipEventRecord(f->ev_small[0], f->stream));
@@ -664,6 +668,7 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
         fr.la_signal = (t > 0) ? base + (uint64_t)t : 0;       // "F(t) has started": F(t-1) is complete
         fr.la_gate = (t > 0) ? base + (uint64_t)t : 0;         // C(t-1) complete before F(t) ends
         fr.lds_min = la_lds;
+        fr.la_late = la_late;
         if (t + 1 < frames) {                                  // the next frame's detections: its support columns of W_t
             fr.next_idx = lm_index_dev + (size_t)(t + 1) * m;
             fr.next_m = m;
@@ -676,7 +681,7 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
         EkfFrame cf = fr;
         cf.cov = cbuf[par];
         cf.cov_out = cbuf[par ^ 1];
-        ekf_launch_cov_update<float>(cf, 2, f->big);
+        ekf_launch_cov_update<float>(cf, pipe_variant, f->big);
         ekf_launch_signal(sync + 1, base + (uint64_t)t + 1, f->big);
         HIP_TRY(hipGetLastError());
     }

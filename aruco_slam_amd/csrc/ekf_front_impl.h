@@ -42,13 +42,19 @@
 
 #define FR_T 512
 #define FR_ALD 66          // row stride (doubles) of the A chunk in LDS
-// doubles of the chunk role's A region (pipelined mode: at least the 128 x 64 f32 support-row tiles of one round)
+#ifndef FR_DOT_RING
+#define FR_DOT_RING 2      // operand chunks (8 k-pairs) in flight, S-block role's support dots (pipelined mode)
+#endif
+// doubles of the chunk role's A region (pipelined mode: before A is built the region holds the staged operands of
+// the support-row product, W_sup [96][128] and W [96][64], and its result [128][64], all f32: 104 KB)
+#define FR_KS 96            // rows of W staged at a time
 __host__ __device__ inline size_t fr_chunk_a_len(int kpad, bool fix) {
-    const size_t a = (size_t)kpad * FR_ALD;
-    return (fix && a < 4096) ? 4096 : a;
+    const size_t a = (size_t)kpad * FR_ALD, st = (size_t)(FR_KS * 128 + FR_KS * 64 + 128 * 64) / 2;
+    return (fix && a < st) ? st : a;
 }
 
 typedef double pf64x4 __attribute__((ext_vector_type(4)));
+typedef float fr_f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ void ekf_poll_sleep() { __builtin_amdgcn_s_sleep(4); }
 // every exchange read is a coherent load (`coherent` kept for readability at the call sites: first
@@ -88,7 +94,7 @@ __device__ __forceinline__ void fr_measure(const EkfFrame& fr, const double* cam
 // ---------------------------------------------------------------------------------------------
 // role: one block of S
 // ---------------------------------------------------------------------------------------------
-template <typename T, int MODEL>
+template <typename T, int MODEL, int NB>
 __device__ __forceinline__ void fr_role_sblock(const EkfFrame& fr, int sb, int nS, double* sm) {
     constexpr int RD = EkfModel<MODEL>::RD, LMD = EkfModel<MODEL>::LMD, JC = EkfModel<MODEL>::JC;
     constexpr int NSLOT = EKF_CAM + LMD * EkfModel<MODEL>::NDET16;
@@ -112,24 +118,36 @@ __device__ __forceinline__ void fr_role_sblock(const EkfFrame& fr, int sb, int n
     // the per-element instruction sequence of the covariance update (ekf_cov_update.hip): the same bits.  Both r and
     // c are support rows of this frame, so the W columns come from the compact copy W_sup[k][slot] that the previous
     // front kernel left behind: row slots {0..9} + [10 + LMD j0, ..), column slots {0..9} + [10 + LMD jc0, ..).
-    // The loads do not depend on the indices: they are in flight during the index -> P round trips.
+    // The sums run on the matrix cores (v_mfma_f32_32x32x2_f32 over k ascending, as in the covariance update), one
+    // wave per 32 x 32 tile of [row slots] x [column slots] -- the LAST waves of the workgroup, beside the index ->
+    // P round trips and the measurement model of the others; their operand loads do not depend on the indices.
+#ifdef FR_NOFIX_S
+    const bool fix = false;
+#else
     const bool fix = sizeof(T) == 4 && fr.wsup_prev != nullptr;
-    float* wr = reinterpret_cast<float*>(rsd + fr.kpad);      // [kpad][NSLOT]  -W_sup[:, row slots]
-    float* wc = wr + fr.kpad * NSLOT;                         // [kpad][NSLOT]   W_sup[:, column slots]
-    float* dots = wc + fr.kpad * NSLOT;                       // [NSLOT][NSLOT]
-    constexpr int NWL = (192 * NSLOT + FR_T - 1) / FR_T;
-    float wrv[NWL], wcv[NWL];
-    if (fix) {
-        const float* __restrict__ wsp = static_cast<const float*>(fr.wsup_prev);
+#endif
+    constexpr int NT = (NSLOT + 31) / 32, DLD = 32 * NT, DR = NB < FR_DOT_RING ? NB : FR_DOT_RING;
+    float* dots = reinterpret_cast<float*>(rsd + fr.kpad);    // [32 NT][32 NT]
+    const int dlane = tid & 63, dl31 = dlane & 31, dlhi = dlane >> 5, dtile = 7 - (tid >> 6);
+    const bool dotw = fix && dtile < NT * NT;
+    float ra[DR][8], rb[DR][8];
+    const float* __restrict__ wsd = static_cast<const float*>(fr.wsup_prev);
+    unsigned aoff = 0, boff = 0;
+    if (dotw) {
         const int smax = fr.wsup_ld - 1;
+        const int rs = 32 * (dtile / NT) + dl31, cs = 32 * (dtile % NT) + dl31;
+        const int gr = (rs < EKF_CAM) ? rs : min(EKF_CAM + LMD * j0 + (rs - EKF_CAM), smax);
+        const int gc = (cs < EKF_CAM) ? cs : min(EKF_CAM + LMD * jc0 + (cs - EKF_CAM), smax);
+        aoff = (unsigned)(dlhi * fr.wsup_ld + gr);      // A: lane (i = l31, k = lhi)
+        boff = (unsigned)(dlhi * fr.wsup_ld + gc);      // B: lane (k = lhi, j = l31)
 #pragma unroll
-        for (int n = 0; n < NWL; ++n) {
-            const int e = min(tid + FR_T * n, fr.kpad * NSLOT - 1), kk = e / NSLOT, sl = e % NSLOT;
-            const int gr = (sl < EKF_CAM) ? sl : min(EKF_CAM + LMD * j0 + (sl - EKF_CAM), smax);
-            const int gc = (sl < EKF_CAM) ? sl : min(EKF_CAM + LMD * jc0 + (sl - EKF_CAM), smax);
-            wrv[n] = wsp[(int64_t)kk * fr.wsup_ld + gr];
-            wcv[n] = wsp[(int64_t)kk * fr.wsup_ld + gc];
-        }
+        for (int c = 0; c < DR; ++c)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float* kb = wsd + (int64_t)(2 * (8 * c + u)) * fr.wsup_ld;      // (wave-uniform: scalar registers)
+                ra[c][u] = kb[aoff];
+                rb[c][u] = kb[boff];
+            }
     }
     if (tid < m) lmc[tid] = ekf_lm_column(fr, LMD, tid, false);
     __syncthreads();
@@ -158,37 +176,33 @@ __device__ __forceinline__ void fr_role_sblock(const EkfFrame& fr, int sb, int n
             for (int b = 0; b < LMD; ++b) pv[n][EKF_CAM + b] = prw[uc20[n] + b];
         }
     }
-    if (fix) {
+    if (dotw) {
+        fr_f32x16 dacc;
 #pragma unroll
-        for (int n = 0; n < NWL; ++n) {
-            const int e = tid + FR_T * n;
-            if (e < fr.kpad * NSLOT) {
-                wr[e] = -wrv[n];
-                wc[e] = wcv[n];
+        for (int r = 0; r < 16; ++r) dacc[r] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dacc = __builtin_amdgcn_mfma_f32_32x32x2f32(-ra[c % DR][u], rb[c % DR][u], dacc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + DR < NB) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float* kb = wsd + (int64_t)(2 * (8 * (c + DR) + u)) * fr.wsup_ld;
+                    ra[c % DR][u] = kb[aoff];
+                    rb[c % DR][u] = kb[boff];
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
+        // C / D layout: register reg <-> tile row (reg & 3) + 8 (reg >> 2) + 4 lhi, column l31
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+            dots[(32 * (dtile / NT) + (reg & 3) + 8 * (reg >> 2) + 4 * dlhi) * DLD + 32 * (dtile % NT) + dl31] = dacc[reg];
     }
     fr_measure<MODEL>(fr, cam, lmc, hs, rsd, tid, false);
     __syncthreads();
     if (fix) {
-        constexpr int NDT = (NSLOT * NSLOT + FR_T - 1) / FR_T;
-        float dacc[NDT];
-        int drs[NDT], dcs[NDT];
-#pragma unroll
-        for (int n = 0; n < NDT; ++n) {
-            const int e = min(tid + FR_T * n, NSLOT * NSLOT - 1);
-            drs[n] = e / NSLOT;
-            dcs[n] = e % NSLOT;
-            dacc[n] = 0.0f;
-        }
-        for (int kk = 0; kk < fr.kpad; ++kk) {
-#pragma unroll
-            for (int n = 0; n < NDT; ++n) dacc[n] = __builtin_fmaf(wr[kk * NSLOT + drs[n]], wc[kk * NSLOT + dcs[n]], dacc[n]);
-        }
-#pragma unroll
-        for (int n = 0; n < NDT; ++n)
-            if (tid + FR_T * n < NSLOT * NSLOT) dots[tid + FR_T * n] = dacc[n];
-        __syncthreads();
 #pragma unroll
         for (int n = 0; n < NE; ++n) {
             if (uact[n]) {
@@ -199,7 +213,7 @@ __device__ __forceinline__ void fr_role_sblock(const EkfFrame& fr, int sb, int n
                     const int col = (b < EKF_CAM) ? b : uc20[n] + (b - EKF_CAM);
                     const int cs = (b < EKF_CAM) ? b : cdet + (b - EKF_CAM);
                     const float q = (col == urho[n]) ? (float)ekf_qdiag(urho[n], fr.dims, fr.nz) : 0.0f;
-                    pv[n][b] = (T)(((float)pv[n][b] + q) + dots[uslot * NSLOT + cs]);
+                    pv[n][b] = (T)(((float)pv[n][b] + q) + dots[uslot * DLD + cs]);
                 }
             }
         }
@@ -271,7 +285,7 @@ __device__ __forceinline__ void fr_role_measure(const EkfFrame& fr, double* sm) 
     int* lmc = reinterpret_cast<int*>(rsd + fr.kpad);
     const int tid = threadIdx.x;
     // pipelined sequence mode: this launch has started, i.e. everything before it on its stream is complete
-    if (fr.la_signal && tid == 0)
+    if (fr.la_signal && !fr.la_late && tid == 0)
         __hip_atomic_store(fr.la_sync, fr.la_signal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     double cam[EKF_CAM];
 #pragma unroll
@@ -398,6 +412,8 @@ struct SvIoFused {
                 settle_block(z1[tc], i1, tc, lane);
                 stale |= fr_tag_stale(t1[tc], fr.seqno);
             }
+        if (C0 == 0 && fr.la_signal && fr.la_late && threadIdx.x == 0)
+            __hip_atomic_store(fr.la_sync, fr.la_signal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         // the residual row (one wave): z - h, replicated in all 16 rows of its "block".  All loads first, THEN the
         // sentinel checks (one round trip)
         if (res0) {
@@ -466,9 +482,38 @@ __device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, double* v_sm)
 // (same fma sequence per t[i] and for dx as the left-looking stand-alone panel kernel).
 // Only wave 0 of the workgroup polls memory for block column q (4 loads per round, so the
 // factorisation's stores are not stuck behind a storm of polls); the other waves watch an LDS word.
+// What a wave of the substitution requests BEFORE the A chunk is built (the requests are in flight during that
+// build): the first blocks of -L of block column 0, (wave 0) Dinv_0 / y_0, and which of the next frame's support
+// slots its column feeds.  A word that has not been published yet arrives as the sentinel and is fetched again.
+template <int NB>
+struct FrPre {
+    static constexpr int LG = (NB >= 11) ? 4 : 6;
+    double lqa[LG][4], dqn[4], yqn[4], tagn;
+    unsigned long long smask;       // next-frame detections whose landmark owns this lane's column (duplicates possible)
+    int sdim;
+};
+template <int NB, int MODEL>
+__device__ __forceinline__ void fr_panel_pre(const EkfFrame& fr, FrPre<NB>& pre, const unsigned long long* smask_l, int wv, int col0, int lane) {
+    const int j = lane & 15, g = lane >> 4;
+    const double* __restrict__ xlop = fr.xl;
+#pragma unroll
+    for (int i = 1; i < NB && i < 1 + FrPre<NB>::LG; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pre.lqa[i - 1][r] = ekf_ldc(xlop + sv_lop_index(i, 0) + r * 64 + lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        pre.dqn[r] = (wv == 0) ? ekf_ldc(fr.xl + fr.xl_dop + (size_t)r * 64 + lane) : 0.0;
+        pre.yqn[r] = (wv == 0) ? ekf_ldc(fr.xl + fr.xl_y + g + 4 * r) : 0.0;
+    }
+    pre.tagn = (wv == 0) ? ekf_ldc(fr.xl + fr.xl_tag + 1) : 0.0;
+    const int mycol = col0 + j;
+    pre.smask = fr.wsup ? smask_l[16 * wv + j] : 0ull;
+    pre.sdim = (mycol >= EKF_CAM) ? (mycol - EKF_CAM) % EkfModel<MODEL>::LMD : 0;
+}
+
 template <typename T, int NB, int MODEL>
 __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds, volatile int* sync, double* pshare,
-                                         int wv, int col0, int lane, int& spin_fail) {
+                                         int wv, int col0, int lane, int& spin_fail, FrPre<NB>& pre) {
     const int j = lane & 15, g = lane >> 4;
     const double* __restrict__ xlop = fr.xl;
     const double* __restrict__ xdop = fr.xl + fr.xl_dop;
@@ -480,20 +525,10 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
     // priority-row kernel reads its A operand coalesced instead of gathering 96 x 106 scattered words per tile.
     // smask: next-frame detections whose landmark owns this lane's column (duplicates possible); cslot: camera slot
     T* __restrict__ wsup = static_cast<T*>(fr.wsup);
-    unsigned long long smask = 0ull;
-    int sdim = 0;
+    const unsigned long long smask = pre.smask;
+    const int sdim = pre.sdim;
     const int mycol = col0 + j;
     const int cslot = (wsup && mycol < EKF_CAM) ? mycol : -1;
-    if (wsup && mycol >= EKF_CAM && mycol < fr.dims) {
-        constexpr int LMD = EkfModel<MODEL>::LMD;
-        const int li = (mycol - EKF_CAM) / LMD;
-        sdim = (mycol - EKF_CAM) % LMD;
-        for (int jj = 0; jj < fr.next_m; ++jj) {
-            int ni = fr.next_idx[jj];
-            if ((unsigned)ni >= (unsigned)fr.n_lm) ni = 0;
-            if (ni == li) smask |= 1ull << jj;
-        }
-    }
     pf64x4 t[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b)
@@ -508,30 +543,69 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
             for (int i = 0; i < 4; ++i) q_old[i] = fr.state[3 + i];
     }
     double part = 0.0;
+    // Prefetch (a chunk that is BEHIND the factorisation -- every chunk in the pipelined sequence mode, whose
+    // prologue is longer -- finds everything published already; fetching Dinv / y, then -L, then computing cost two
+    // dependent memory round trips per block column, 2.2 - 2.8 us): the first LG blocks of -L of block column q + 1
+    // and (wave 0) its Dinv / y are requested during step q.  A word that has not been published yet reads as the
+    // sentinel: such a column goes through the polling path exactly as before.
+    constexpr int LG = FrPre<NB>::LG;
+    constexpr bool AHEAD = NB <= 8;                 // two register sets for -L (else: requested at the top of its own step)
+    auto& lqa = pre.lqa;
+    auto& dqn = pre.dqn;
+    auto& yqn = pre.yqn;
+    double lqb[AHEAD ? LG : 1][4];
+    auto issue_l = [&](auto& lq, int q) {
+#pragma unroll
+        for (int i = q + 1; i < NB && i < q + 1 + LG; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lq[i - q - 1][r] = ekf_ldc(xlop + sv_lop_index(i, q) + r * 64 + lane);
+    };
+    auto issue_d = [&](int q) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dqn[r] = ekf_ldc(xdop + (size_t)(q * 4 + r) * 64 + lane);
+            yqn[r] = ekf_ldc(xy + 16 * q + g + 4 * r);
+        }
+        pre.tagn = ekf_ldc(fr.xl + fr.xl_tag + 1 + q);      // (checked when the column is used: a load that is used at once
+                                                             // would make the wave wait for everything it has just requested)
+    };
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
         double dq[4], yq[4];
+        if (!AHEAD && q > 0) issue_l(lqa, q);
         if (wv == 0) {
             // sync[0] = block columns shared so far, sync[1] = reads of the shared slot acknowledged
-            int it = 0;
-            if (q < NB - 1)      // (the last block column is polled on the data itself: one round trip less)
-                while (ekf_is_sent(ekf_ldc(xdop + (size_t)(q * 4 + 3) * 64 + 63))) {      // the word written last
-                    if (++it > EKF_SPIN_MAX) { spin_fail = 1; break; }
+            bool pend = false;
+            double tag = pre.tagn;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dq[r] = dqn[r];
+                yq[r] = yqn[r];
+                pend = pend || ekf_is_sent(dq[r]) || ekf_is_sent(yq[r]);
+            }
+            if (__any(pend)) {
+                int it = 0;
+                if (q < NB - 1)      // (the last block column is polled on the data itself: one round trip less)
+                    while (ekf_is_sent(ekf_ldc(xdop + (size_t)(q * 4 + 3) * 64 + 63))) {      // the word written last
+                        if (++it > EKF_SPIN_MAX) { spin_fail = 1; break; }
+                        ekf_poll_sleep();
+                    }
+                for (it = 0;; ++it) {
+                    pend = false;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        dq[r] = ekf_ldc(xdop + (size_t)(q * 4 + r) * 64 + lane);
+                        yq[r] = ekf_ldc(xy + 16 * q + g + 4 * r);
+                        pend = pend || ekf_is_sent(dq[r]) || ekf_is_sent(yq[r]);
+                    }
+                    if (!__any(pend)) break;
+                    if (it > EKF_SPIN_MAX) { spin_fail = 1; break; }
                     ekf_poll_sleep();
                 }
-            for (it = 0;; ++it) {
-                bool pend = false;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    dq[r] = ekf_ldt(xdop + (size_t)(q * 4 + r) * 64 + lane, it > 0 || q == NB - 1);
-                    yq[r] = ekf_ldt(xy + 16 * q + g + 4 * r, it > 0 || q == NB - 1);
-                    pend = pend || ekf_is_sent(dq[r]) || ekf_is_sent(yq[r]);
-                }
-                if (!__any(pend)) break;
-                if (it > EKF_SPIN_MAX) { spin_fail = 1; break; }
-                ekf_poll_sleep();
+                tag = ekf_ldc(fr.xl + fr.xl_tag + 1 + q);
             }
-            it = 0;
+            if (lane == 0 && fr_tag_stale(tag, fr.seqno)) atomicOr(fr.status, EKF_ST_STALE_COL);
+            int it = 0;
             while (sync[1] < 3 * q) {                  // the slot's previous content has been read
                 if (++it > 64 * EKF_SPIN_MAX) { spin_fail = 1; break; }
                 __builtin_amdgcn_s_sleep(1);
@@ -544,6 +618,7 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the slot before the word that announces it
             if (lane == 0) sync[0] = q + 1;
+            if (q + 1 < NB) issue_d(q + 1);
         } else {
             int it = 0;
             while (sync[0] < q + 1) {
@@ -559,9 +634,9 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the reads before the acknowledgement
             if (lane == 0) atomicAdd(const_cast<int*>(sync) + 1, 1);
         }
-        if (wv == 0 && lane == 0) {
-            const double tag = ekf_ldc(fr.xl + fr.xl_tag + 1 + q);
-            if (fr_tag_stale(tag, fr.seqno)) atomicOr(fr.status, EKF_ST_STALE_COL);
+        if (AHEAD && q + 1 < NB) {                   // (before this step's W stores: a wait for a load also waits for every older store)
+            if ((q & 1) == 0) issue_l(lqb, q + 1);
+            else issue_l(lqa, q + 1);
         }
         pf64x4 wq = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -580,19 +655,16 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
             }
         }
         // t[i] += (-L_iq) W_q for i > q, at most LG blocks of -L in registers at a time (the whole
-        // kernel has to stay clear of register spills)
-        constexpr int LG = (NB >= 11) ? 4 : 6;
-#pragma unroll
-        for (int i0 = q + 1; i0 < NB; i0 += LG) {
-            double lq[LG][4];
+        // kernel has to stay clear of register spills); the first LG were requested a step ago
+        auto apply = [&](auto& lq, int i0, bool fresh) {
             int it = 0;
-            for (;;) {      // normally one pass: the -L blocks of column q were published before Dinv
+            for (;; fresh = true) {      // normally one pass
                 bool pend = false;
 #pragma unroll
                 for (int i = i0; i < NB && i < i0 + LG; ++i)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        lq[i - i0][r] = ekf_ldt(xlop + sv_lop_index(i, q) + r * 64 + lane, it > 0);
+                        if (fresh) lq[i - i0][r] = ekf_ldc(xlop + sv_lop_index(i, q) + r * 64 + lane);
                         pend = pend || ekf_is_sent(lq[i - i0][r]);
                     }
                 if (!__any(pend)) break;
@@ -604,6 +676,15 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     t[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(lq[i - i0][r], wq[r], t[i], 0, 0, 0);
+        };
+        if (q + 1 < NB) {
+            if (AHEAD && (q & 1)) apply(lqb, q + 1, false);
+            else apply(lqa, q + 1, false);
+        }
+#pragma unroll
+        for (int i0 = q + 1 + LG; i0 < NB; i0 += LG) {
+            double lq[LG][4];
+            apply(lq, i0, true);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) part = __builtin_fma(wq[r], yq[r], part);
@@ -641,126 +722,31 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
     if (stp) stp[NB] = wall_clock64();
 }
 
-// Pipelined sequence mode: one 32 x 32 tile of the CURRENT covariance's support rows, [32 slots] x [32 columns of this
-// chunk], from the previous frame's P and W (see fr_role_sblock):  (P_prev + Q) + sum_k fma(-W_sup[k][slot], W[k][col]),
-// v_mfma_f32_32x32x2_f32 over k in ascending order -- per element the instruction sequence of ekf_cov_update_mfma_f32
-// (for an element above the diagonal that kernel runs the mirrored product: the same bits).  One wave; the result goes
-// to `pl` ([128 slots of this round][64 columns], f32) in LDS.  A operand: lane (i = l31, k = lhi) from W_sup; B operand:
-// lane (k = lhi, j = l31) from the W panel; ring of D chunks of 8 k-pairs in flight.
-typedef float fr_f32x16 __attribute__((ext_vector_type(16)));
-template <int NB, int MODEL>
-__device__ __forceinline__ void fr_rows_tile(const EkfFrame& fr, const int* lmc, float* pl, int tile_i, int tile_l, int j0, int jl,
-                                             int lane, int nslots) {
-    constexpr int LMD = EkfModel<MODEL>::LMD, KB = NB, D = KB < 4 ? KB : 4;
-    const int l31 = lane & 31, lhi = lane >> 5;
-    const float* __restrict__ P = static_cast<const float*>(fr.cov);
-    const int64_t ld = fr.ld, ldw = fr.ldw, lds = fr.wsup_ld;
-    const float* wa = static_cast<const float*>(fr.wsup_prev) + (int64_t)lhi * lds + 32 * tile_i + l31;
-    const float* wb = static_cast<const float*>(fr.wprev) + (int64_t)lhi * ldw + j0 + l31;
-    float ra[D][8], rb[D][8];
-#pragma unroll
-    for (int c = 0; c < D; ++c)
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            ra[c][u] = wa[(int64_t)(2 * (8 * c + u)) * lds];
-            rb[c][u] = wb[(int64_t)(2 * (8 * c + u)) * ldw];
-        }
-    // C / D layout: register reg <-> tile row (reg & 3) + 8 (reg >> 2) + 4 lhi, column l31
-    float pt[16];
-    int prow_of[16];
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int slot = 32 * tile_i + (reg & 3) + 8 * (reg >> 2) + 4 * lhi;
-        const int sj = min(max((slot - EKF_CAM) / LMD, 0), fr.m - 1);
-        prow_of[reg] = (slot < EKF_CAM) ? slot : (slot < nslots ? lmc[sj] + (slot - EKF_CAM) % LMD : 0);
-        pt[reg] = P[(int64_t)prow_of[reg] * ld + j0 + l31];
-    }
-    fr_f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-    for (int c = 0; c < KB; ++c) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-ra[c % D][u], rb[c % D][u], acc, 0, 0, 0);
-        if (c + D < KB) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                ra[c % D][u] = wa[(int64_t)(2 * (8 * (c + D) + u)) * lds];
-                rb[c % D][u] = wb[(int64_t)(2 * (8 * (c + D) + u)) * ldw];
-            }
-        }
-    }
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int rl = (reg & 3) + 8 * (reg >> 2) + 4 * lhi;
-        const float q = (prow_of[reg] == j0 + l31) ? (float)ekf_qdiag(prow_of[reg], fr.dims, fr.nz) : 0.0f;
-        pl[(32 * tile_l + rl) * 64 + jl + l31] = (pt[reg] + q) + acc[reg];
-    }
-}
-
 template <typename T, int NU, int MODEL, int NB>
 __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, double* sm) {
     constexpr int RD = EkfModel<MODEL>::RD, LMD = EkfModel<MODEL>::LMD, JC = EkfModel<MODEL>::JC;
     constexpr int NWV = FR_T / 64;
     double* hs = sm;                                    // [k][JC]
     double* a_lds = sm + fr.k * JC;                     // [kpad][FR_ALD]; before A is built: the support-row tiles (pipelined mode)
+#ifdef FR_NOFIX_C
+    const bool fix = false;
+#else
     const bool fix = sizeof(T) == 4 && fr.wprev != nullptr;
+#endif
     const size_t a_len = fr_chunk_a_len(fr.kpad, fix);
     int* lmc = reinterpret_cast<int*>(a_lds + a_len);
     int* flag = lmc + 64;                               // [0] last-chunk flag, [1..2] panel sync words
     double* pshare = reinterpret_cast<double*>(lmc + 72);   // [8][64] Dinv operands and y of one block column
+    unsigned long long* smask_l = reinterpret_cast<unsigned long long*>(pshare + 8 * 64);      // [64] per column of the chunk
+    int* nidx = reinterpret_cast<int*>(smask_l + 64);       // [64] the next frame's landmark indices
     const int tid = threadIdx.x, m = fr.m;
     const int chunk0 = chunk * 64, cl = tid & 63, c = chunk0 + cl, g = tid >> 6;
     const T* __restrict__ P = static_cast<const T*>(fr.cov);
     const int64_t ld = fr.ld;
     if (fr.stamps && chunk == 0 && tid == 0) fr.stamps[32] = wall_clock64();
-    T pcr[EKF_CAM];
-    T plr[NU][LMD];
-    if (!fix) {
-#pragma unroll
-        for (int a = 0; a < EKF_CAM; ++a) pcr[a] = P[a * ld + c];
-    }
-    if (tid < m) lmc[tid] = ekf_lm_column(fr, LMD, tid, false);
-    if (tid == 0) { flag[1] = 0; flag[2] = 0; }
-    __syncthreads();
-    if (!fix) {
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int ju = min(g + NWV * u, m - 1);
-            const int c0 = lmc[ju];
-#pragma unroll
-            for (int d = 0; d < LMD; ++d) plr[u][d] = P[(int64_t)(c0 + d) * ld + c];
-        }
-    } else if constexpr (sizeof(T) == 4) {
-        // Pipelined sequence mode: `cov` is the PREVIOUS frame's P; the support rows of the current one (10 + LMD m
-        // slots x this chunk's 64 columns) are completed on the matrix cores, 128 slots per round: 8 tiles, one per
-        // wave, through LDS (the region that becomes the A chunk afterwards), from where every thread takes the rows
-        // of its detections.
-        float* pl = reinterpret_cast<float*>(a_lds);
-        const int nslots = EKF_CAM + LMD * m;
-        for (int round = 0; 128 * round < nslots; ++round) {
-            const int tile_l = g >> 1, tile_i = 4 * round + tile_l, jl = 32 * (g & 1);
-            if (32 * tile_i < nslots) fr_rows_tile<NB, MODEL>(fr, lmc, pl, tile_i, tile_l, chunk0 + jl, jl, tid & 63, nslots);
-            __syncthreads();
-            if (round == 0) {
-#pragma unroll
-                for (int a = 0; a < EKF_CAM; ++a) pcr[a] = (T)pl[a * 64 + cl];
-            }
-#pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                const int ju = min(g + NWV * u, m - 1);
-#pragma unroll
-                for (int d = 0; d < LMD; ++d) {
-                    const int slot = EKF_CAM + LMD * ju + d;
-                    if ((slot >> 7) == round) plr[u][d] = (T)pl[(slot & 127) * 64 + cl];
-                }
-            }
-            __syncthreads();
-        }
-    }
-    // Jacobian rows: published by S-block workgroup 0 (this role never reads the state, so the
+    // Jacobian rows: published by the measurement workgroup (this role never reads the state, so the
     // injection at the end of the launch cannot race with a chunk that starts late)
-    {
+    auto fetch_jacobian = [&]() {
         const double* __restrict__ xj = fr.xl + fr.xl_jac;
         const int nel = fr.k * JC;
         int spin = 0;
@@ -783,13 +769,158 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
             hs[e] = v;
         }
         if (spin) atomicOr(fr.status, EKF_ST_TIMEOUT);
+        if (fr.stamps && chunk == 0 && tid == 0 && NB <= 6) fr.stamps[44] = wall_clock64();
         if (tid == 0) {
             const double tag = ekf_ldc(fr.xl + fr.xl_tag);
             if (fr_tag_stale(tag, fr.seqno)) atomicOr(fr.status, EKF_ST_STALE_JAC);
         }
+    };
+    T pcr[EKF_CAM];
+    T plr[NU][LMD];
+    if (!fix) {
+#pragma unroll
+        for (int a = 0; a < EKF_CAM; ++a) pcr[a] = P[a * ld + c];
     }
+    if (tid < m) lmc[tid] = ekf_lm_column(fr, LMD, tid, false);
+    if (fr.wsup && tid >= 64 && tid < 64 + fr.next_m) {     // (the next frame's indices, for the support-column copy of W)
+        int ni = fr.next_idx[tid - 64];
+        nidx[tid - 64] = ((unsigned)ni >= (unsigned)fr.n_lm) ? 0 : ni;
+    }
+    if (tid == 0) { flag[1] = 0; flag[2] = 0; }
     __syncthreads();
+    if (fr.wsup && tid < 64) {      // next-frame detections whose landmark owns column c (duplicates possible)
+        unsigned long long mk = 0ull;
+        if (c >= EKF_CAM && c < fr.dims) {
+            const int li = (c - EKF_CAM) / LMD;
+            for (int jj = 0; jj < fr.next_m; ++jj) mk |= (unsigned long long)(nidx[jj] == li) << jj;
+        }
+        smask_l[tid] = mk;
+    }
+    if (!fix) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int ju = min(g + NWV * u, m - 1);
+            const int c0 = lmc[ju];
+#pragma unroll
+            for (int d = 0; d < LMD; ++d) plr[u][d] = P[(int64_t)(c0 + d) * ld + c];
+        }
+    } else if constexpr (sizeof(T) == 4) {
+        // Pipelined sequence mode: `cov` is the PREVIOUS frame's P; the support rows of the current one (10 + LMD m
+        // slots x this chunk's 64 columns) are completed on the matrix cores:
+        //     (P_prev + Q) + sum_k fma(-W_sup[k][slot], W[k][col]),   v_mfma_f32_32x32x2_f32 over k in ascending order
+        // -- per element the instruction sequence of ekf_cov_update_mfma_f32 (for an element above the diagonal that
+        // kernel runs the mirrored product: the same bits).  128 slots per round: 8 tiles of 32 x 32, one per wave.
+        // The operands are staged through LDS by the whole workgroup, 96 rows of W at a time, 16 bytes per lane and all
+        // loads in flight together: ONE memory round trip per stage (a first version fed the MFMAs from a register
+        // ring straight from the L2: 6.3 us per tile beside the covariance update of the previous frame, 1.3 us of
+        // them matrix work).  The result goes through LDS too (the region becomes the A chunk afterwards); every
+        // thread takes the rows of its detections from there.
+        typedef float fr_f4 __attribute__((ext_vector_type(4)));
+        float* sA = reinterpret_cast<float*>(a_lds);      // [FR_KS][128]  W_sup rows, this round's slots
+        float* sB = sA + FR_KS * 128;                     // [FR_KS][64]   W rows, this chunk's columns
+        float* pl = sB + FR_KS * 64;                      // [128][64]     support rows of the current P
+        const float* __restrict__ wsa = static_cast<const float*>(fr.wsup_prev);
+        const float* __restrict__ wpb = static_cast<const float*>(fr.wprev);
+        const float* __restrict__ Pf = static_cast<const float*>(fr.cov);
+        const int nslots = EKF_CAM + LMD * m;
+        const int lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+        const bool stp_c = fr.stamps && chunk == 0 && tid == 0 && NB <= 6;
+        if (stp_c) fr.stamps[41] = wall_clock64();
+        for (int round = 0; 128 * round < nslots; ++round) {
+            const int tile_l = g >> 1, tile_i = 4 * round + tile_l, jl = 32 * (g & 1);
+            const bool tile_ok = 32 * tile_i < nslots;
+            fr_f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            float pt[16];
+#pragma unroll
+            for (int kb = 0; kb < NB; kb += FR_KS / 16) {
+                constexpr int NA = FR_KS * 32 / FR_T, NBL = FR_KS * 16 / FR_T;      // 16-byte loads per thread
+                const int rows = min(FR_KS, fr.kpad - 16 * kb);
+                fr_f4 va[NA], vb[NBL];
+#pragma unroll
+                for (int n = 0; n < NA; ++n) {
+                    const int e = tid + FR_T * n, row = min(e >> 5, rows - 1), c4 = e & 31;
+                    const int col = min(128 * round + 4 * c4, fr.wsup_ld - 4);
+                    va[n] = *reinterpret_cast<const fr_f4*>(wsa + (int64_t)(16 * kb + row) * fr.wsup_ld + col);
+                }
+#pragma unroll
+                for (int n = 0; n < NBL; ++n) {
+                    const int e = tid + FR_T * n, row = min(e >> 4, rows - 1), c4 = e & 15;
+                    vb[n] = *reinterpret_cast<const fr_f4*>(wpb + (int64_t)(16 * kb + row) * fr.ldw + chunk0 + 4 * c4);
+                }
+                if (kb == 0 && tile_ok) {
+                    // C / D layout: register reg <-> tile row (reg & 3) + 8 (reg >> 2) + 4 lhi, column l31
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int slot = 32 * tile_i + (reg & 3) + 8 * (reg >> 2) + 4 * lhi;
+                        const int sj = min(max((slot - EKF_CAM) / LMD, 0), m - 1);
+                        const int prw = (slot < EKF_CAM) ? slot : (slot < nslots ? lmc[sj] + (slot - EKF_CAM) % LMD : 0);
+                        pt[reg] = Pf[(int64_t)prw * ld + chunk0 + jl + l31];
+                    }
+                }
+                // the Jacobian rows arrive while the stage is in flight (hs is a region of its own)
+                if (kb == 0 && round == 0) fetch_jacobian();
+                if (kb > 0) __syncthreads();                   // the previous stage has been consumed
+#pragma unroll
+                for (int n = 0; n < NA; ++n) *reinterpret_cast<fr_f4*>(sA + 4 * (tid + FR_T * n)) = va[n];
+#pragma unroll
+                for (int n = 0; n < NBL; ++n) *reinterpret_cast<fr_f4*>(sB + 4 * (tid + FR_T * n)) = vb[n];
+                __syncthreads();
+                if (stp_c && round == 0 && kb == 0) fr.stamps[45] = wall_clock64();
+                if (tile_ok) {
+#pragma unroll
+                    for (int c = kb; c < NB && c < kb + FR_KS / 16; ++c) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int kr = 16 * (c - kb) + 2 * u + lhi;      // A: lane (i = l31, k = lhi); B: lane (k = lhi, j = l31)
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-sA[kr * 128 + 32 * tile_l + l31], sB[kr * 64 + jl + l31], acc, 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);      // (the scheduler would hoist every LDS read of the stage: 16 registers per chunk)
+                    }
+                }
+            }
+            if (stp_c && round == 0) fr.stamps[46] = wall_clock64();
+            if (tile_ok) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int rl = (reg & 3) + 8 * (reg >> 2) + 4 * lhi, slot = 32 * tile_i + rl;
+                    const int sj = min(max((slot - EKF_CAM) / LMD, 0), m - 1);
+                    const int prw = (slot < EKF_CAM) ? slot : (slot < nslots ? lmc[sj] + (slot - EKF_CAM) % LMD : 0);
+                    const float q = (prw == chunk0 + jl + l31) ? (float)ekf_qdiag(prw, fr.dims, fr.nz) : 0.0f;
+                    pl[(32 * tile_l + rl) * 64 + jl + l31] = (pt[reg] + q) + acc[reg];
+                }
+            }
+            if (stp_c && round == 0) fr.stamps[42] = wall_clock64();
+            __syncthreads();
+            if (stp_c && round == 0) fr.stamps[43] = wall_clock64();
+            if (round == 0) {
+#pragma unroll
+                for (int a = 0; a < EKF_CAM; ++a) pcr[a] = (T)pl[a * 64 + cl];
+            }
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int ju = min(g + NWV * u, m - 1);
+#pragma unroll
+                for (int d = 0; d < LMD; ++d) {
+                    const int slot = EKF_CAM + LMD * ju + d;
+                    if ((slot >> 7) == round) plr[u][d] = (T)pl[(slot & 127) * 64 + cl];
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (!fix) fetch_jacobian();
+    __syncthreads();
+    FrPre<NB> pre;
+    if (fr.stamps && chunk == 0 && tid == 0 && NB <= 6) fr.stamps[14] = wall_clock64();
+    if (g < 4) fr_panel_pre<NB, MODEL>(fr, pre, smask_l, g, chunk0 + 16 * g, tid & 63);
+    if (fr.stamps && chunk == 0 && tid == 0 && NB <= 6) fr.stamps[15] = wall_clock64();
     double pc[EKF_CAM];
+    // (hs is only read and the A chunk only written here: without `restrict` every row's Jacobian reads waited for the
+    // previous row's store)
+    const double* __restrict__ hsr = hs;
+    double* __restrict__ aw = a_lds;
 #pragma unroll
     for (int a = 0; a < EKF_CAM; ++a) pc[a] = (double)pcr[a] + ((a == c) ? ekf_qdiag(a, fr.dims, fr.nz) : 0.0);
 #pragma unroll
@@ -803,24 +934,24 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
 #pragma unroll
             for (int d = 0; d < RD; ++d) {
                 const int r = RD * j + d;
-                const double* hr = hs + r * JC;
+                const double* __restrict__ hr = hsr + r * JC;
                 double acc = 0.0;
 #pragma unroll
                 for (int a = 0; a < EKF_CAM; ++a) acc = __builtin_fma(hr[a], pc[a], acc);
 #pragma unroll
                 for (int e = 0; e < LMD; ++e) acc = __builtin_fma(hr[10 + e], pl[e], acc);
-                a_lds[r * FR_ALD + cl] = acc;
+                aw[r * FR_ALD + cl] = acc;
                 if (fr.wdbg) fr.amat[(int64_t)r * fr.lda + c] = acc;
             }
         }
     }
-    for (int r = fr.k + g; r < fr.kpad; r += NWV) a_lds[r * FR_ALD + cl] = 0.0;
+    for (int r = fr.k + g; r < fr.kpad; r += NWV) aw[r * FR_ALD + cl] = 0.0;
     __syncthreads();
     if (fr.stamps && chunk == 0 && tid == 0) fr.stamps[33] = wall_clock64();
     int spin_fail = 0;
     if (g < 4) {
         const int lane = tid & 63, col0 = chunk0 + 16 * g;
-        fr_panel<T, NB, MODEL>(fr, a_lds, flag + 1, pshare, g, col0, lane, spin_fail);
+        fr_panel<T, NB, MODEL>(fr, a_lds, flag + 1, pshare, g, col0, lane, spin_fail, pre);
         if (spin_fail && (tid & 63) == 0) atomicOr(fr.status, EKF_ST_TIMEOUT);
     }
     if (MODEL == 0) return;
@@ -867,7 +998,7 @@ __global__ __launch_bounds__(FR_T) void ekf_front_kernel(EkfFrame fr) {
     const int nb = fr.kpad / EKF_RB, nS = nb * (nb + 1) / 2;
     const int bx = blockIdx.x;
     if (bx == 0) fr_role_measure<MODEL>(fr, fr_sm);
-    else if (bx <= nS) fr_role_sblock<T, MODEL>(fr, bx - 1, nS, fr_sm);
+    else if (bx <= nS) fr_role_sblock<T, MODEL, NB>(fr, bx - 1, nS, fr_sm);
     else if (bx == nS + 1) fr_role_factor<NB>(fr, fr_sm);
     else fr_role_chunk<T, NU, MODEL, NB>(fr, bx - nS - 2, fr_sm);
 }
@@ -885,8 +1016,8 @@ static void ekf_front_go(const EkfFrame& fr, hipStream_t s) {
     const int nb = fr.kpad / EKF_RB, nS = nb * (nb + 1) / 2;
     const bool fix = sizeof(T) == 4 && fr.wprev != nullptr;
     const size_t lds_s = ((size_t)fr.k * JC + NSLOT * 16 + 32 + fr.kpad) * 8 + 16 +
-                         (fix ? ((size_t)2 * fr.kpad * NSLOT + NSLOT * NSLOT) * 4 : 0);
-    const size_t lds_c = ((size_t)fr.k * JC + fr_chunk_a_len(fr.kpad, fix)) * 8 + 72 * 4 + 8 * 64 * 8 + 16;
+                         (fix ? (size_t)(32 * ((NSLOT + 31) / 32)) * (32 * ((NSLOT + 31) / 32)) * 4 : 0);
+    const size_t lds_c = ((size_t)fr.k * JC + fr_chunk_a_len(fr.kpad, fix)) * 8 + 72 * 4 + 8 * 64 * 8 + 64 * 8 + 64 * 4 + 16;
     const size_t lds_f = (size_t)sv_lds_doubles(NB) * 8;
     size_t lds = lds_s > lds_c ? lds_s : lds_c;
     if (lds_f > lds) lds = lds_f;

@@ -7,7 +7,14 @@ s=SyntheticStream(n,m,seed=0)
 f=EKF(np.array([0,0,0,1,0,0,0,0,0,0]),max_landmarks=n,max_visible=m,cov_dtype="float32")
 (f.backend.debug_enable_w if len(sys.argv) > 1 and sys.argv[1] == 'debug' else f.backend.debug_enable_stamps)()
 for ids,p in s.bootstrap(): f.observe(ids,p)
-for ids,p in s.steady(5): f.observe(ids,p)
+if len(sys.argv) > 1 and sys.argv[1] == 'seq':      # the last frame of a pipelined sequence (beside the previous frame's covariance update)
+    import torch
+    frames = list(s.steady(40))
+    idx = torch.tensor(np.stack([x[0] for x in frames]), dtype=torch.int32, device="cuda")
+    z = torch.tensor(np.stack([x[1][:, :3] for x in frames]), dtype=torch.float64, device="cuda")
+    f.backend.observe_sequence(idx, z, None); f.backend.sync()
+else:
+    for ids,p in s.steady(5): f.observe(ids,p)
 st=f.backend.debug_fetch("stamps",m)
 nb=6
 t0=min(st[62],st[32],st[60])
@@ -20,6 +27,6 @@ for b in range(nb):
     prev = st[1] if b == 0 else st[3+2*(b-1)]
     print("  col",b," chain phase + barrier",st[2+2*b]-prev," panel + barrier + urgent update",st[3+2*b]-st[2+2*b],
           ("  (chain alone %d)" % (st[48+2*b]-st[47+2*b])) if b < 4 else "")
-print("chunk0: start",us(32)," A in LDS",us(33))
+print("chunk0: start",us(32)," indices in LDS",us(41)," operands staged",us(45)," MFMAs done",us(46)," tile done (wave 0)",us(42)," all tiles",us(43)," Jacobian in LDS",us(44)," picked",us(14)," prefetch issued",us(15)," A in LDS",us(33))
 for q in range(nb): print("  step",q,"done",us(34+q))
 print("  W/dx stored",us(34+nb))
