@@ -650,9 +650,9 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
     static const char* late_env = getenv("EKF_LA_LATE");          // (experiments)
     const int la_late = late_env ? atoi(late_env) : 0;
     const int la_lds = la_env ? atoi(la_env) * 1024 : (grid_now <= 100 ? 148 * 1024 : 0);
-    // stream B starts from everything that is on stream A now (the previous call ended with the reverse join)
-    HIP_TRY(hipEventRecord(f->ev_small[0], f->stream));
-    HIP_TRY(hipStreamWaitEvent(f->big, f->ev_small[0], 0));
+    // (stream B needs no edge from stream A at the start: its first launch is the gate in front of C(0), which waits
+    // for "F(1) has started", i.e. for everything that is on stream A now and F(0); the previous call ended with
+    // stream A waiting for stream B)
     for (int t = 0; t < frames; ++t) {
         const int par = t & 1;
         EkfFrame fr = make_frame(f, lm_index_dev + (size_t)t * m, z_dev + (size_t)t * m * L.rd, m,
@@ -682,16 +682,18 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
         cf.cov = cbuf[par];
         cf.cov_out = cbuf[par ^ 1];
         ekf_launch_cov_update<float>(cf, pipe_variant, f->big);
+        // an odd number of frames leaves the covariance in the internal buffer: back into the caller's
+        if (t + 1 == frames && (frames & 1))
+            HIP_TRY(hipMemcpyAsync(f->cov, cbuf[1], (size_t)L.cap * L.cap * L.elem, hipMemcpyDeviceToDevice, f->big));
         ekf_launch_signal(sync + 1, base + (uint64_t)t + 1, f->big);
         HIP_TRY(hipGetLastError());
     }
     f->la_base = base + (uint64_t)frames;
-    // an odd number of frames leaves the covariance in the internal buffer: back into the caller's
-    if (frames & 1)
-        HIP_TRY(hipMemcpyAsync(f->cov, cbuf[1], (size_t)L.cap * L.cap * L.elem, hipMemcpyDeviceToDevice, f->big));
-    // join: everything later on the main stream (and every getter) sees the final covariance
-    HIP_TRY(hipEventRecord(f->ev_big[0], f->big));
-    HIP_TRY(hipStreamWaitEvent(f->stream, f->ev_big[0], 0));
+    // join: everything later on the main stream (and every getter) sees the final covariance -- a gate on stream A
+    // that waits for the last signal of stream B (an event pair costs ~13 us, the gate ~1 us; the kernel boundary
+    // behind the gate gives the memory ordering, as inside the sequence)
+    ekf_launch_gate(sync + 1, base + (uint64_t)frames, status, f->stream);
+    HIP_TRY(hipGetLastError());
     f->last_m = m;
     return EKF_OK;
 }

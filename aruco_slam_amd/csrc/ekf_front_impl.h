@@ -914,23 +914,29 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
     __syncthreads();
     FrPre<NB> pre;
     if (fr.stamps && chunk == 0 && tid == 0 && NB <= 6) fr.stamps[14] = wall_clock64();
+    // (the support rows become doubles BEFORE the substitution's first requests go out: they may come straight from
+    // memory, and a wait for them placed after those requests would wait for the requests too)
+    double pc[EKF_CAM], pld[NU][LMD];
+#pragma unroll
+    for (int a = 0; a < EKF_CAM; ++a) pc[a] = (double)pcr[a] + ((a == c) ? ekf_qdiag(a, fr.dims, fr.nz) : 0.0);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int c0 = lmc[min(g + NWV * u, m - 1)];
+#pragma unroll
+        for (int d = 0; d < LMD; ++d) pld[u][d] = (double)plr[u][d] + ((c0 + d == c) ? fr.nz.q_lm : 0.0);
+    }
+    asm volatile("" ::: "memory");
     if (g < 4) fr_panel_pre<NB, MODEL>(fr, pre, smask_l, g, chunk0 + 16 * g, tid & 63);
     if (fr.stamps && chunk == 0 && tid == 0 && NB <= 6) fr.stamps[15] = wall_clock64();
-    double pc[EKF_CAM];
     // (hs is only read and the A chunk only written here: without `restrict` every row's Jacobian reads waited for the
     // previous row's store)
     const double* __restrict__ hsr = hs;
     double* __restrict__ aw = a_lds;
 #pragma unroll
-    for (int a = 0; a < EKF_CAM; ++a) pc[a] = (double)pcr[a] + ((a == c) ? ekf_qdiag(a, fr.dims, fr.nz) : 0.0);
-#pragma unroll
     for (int u = 0; u < NU; ++u) {
         const int j = g + NWV * u;
         if (j < m) {
-            const int c0 = lmc[j];
-            double pl[LMD];
-#pragma unroll
-            for (int d = 0; d < LMD; ++d) pl[d] = (double)plr[u][d] + ((c0 + d == c) ? fr.nz.q_lm : 0.0);
+            const double (&pl)[LMD] = pld[u];
 #pragma unroll
             for (int d = 0; d < RD; ++d) {
                 const int r = RD * j + d;

@@ -172,11 +172,11 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(w_steps, w_steps + k_steps)
-    hip.sync()
-    torch.cuda.synchronize()
+    torch.cuda.synchronize()          # (every stream of the device, the filter's internal one included)
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    hip.sync()                        # status word of the filter: raises if any frame of the timed region failed
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
