@@ -10,7 +10,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB_DIR = PKG / "lib"
 LIB_PATH = LIB_DIR / "libekf_slam_hip.so"
-SOURCES = ["ekf_api.hip", "ekf_small_kernels.hip", "ekf_front.hip", "ekf_front_f64.hip", "ekf_cov_update.hip"]
+SOURCES = ["ekf_api.hip", "ekf_small_kernels.hip", "ekf_front.hip", "ekf_front_f64.hip", "ekf_cov_update.hip", "ekf_pose_ippe.hip"]
 HEADERS = ["ekf_device.h", "ekf_kernels.h", "ekf_solve_device.h", "ekf_front_impl.h", "../../include/ekf_slam_hip.h"]
 
 
@@ -47,7 +47,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
             if verbose:
                 print(" ".join(cmd))
             subprocess.run(cmd, check=True)
-        with ThreadPoolExecutor(max_workers=min(5, len(jobs))) as pool:
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as pool:
             list(pool.map(run, jobs))
     if force or _stale(LIB_PATH, objs):
         cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB_PATH),

@@ -698,6 +698,55 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
     return EKF_OK;
 }
 
+// ---- detection -> pose front end (base_filter.py:92-171): stateless, no filter handle -------------------------
+static int make_camera(const double camera_matrix[9], const double* dist_coeffs, int32_t n_dist, EkfCamera* cam) {
+    if (!camera_matrix) return fail(EKF_ERR_INVALID, "camera matrix is NULL");
+    if (n_dist < 0 || n_dist > 8 || (n_dist > 0 && !dist_coeffs))
+        return fail(EKF_ERR_INVALID, "0..8 distortion coefficients (k1 k2 p1 p2 k3 k4 k5 k6) are supported");
+    if (!(camera_matrix[0] > 0.0) || !(camera_matrix[4] > 0.0)) return fail(EKF_ERR_INVALID, "focal lengths must be > 0");
+    cam->fx = camera_matrix[0];
+    cam->fy = camera_matrix[4];
+    cam->cx = camera_matrix[2];
+    cam->cy = camera_matrix[5];
+    for (int i = 0; i < 8; ++i) cam->k[i] = (i < n_dist) ? dist_coeffs[i] : 0.0;
+    return EKF_OK;
+}
+
+int ekf_estimate_poses_device(const double* corners_dev, int32_t count, double marker_size, const double camera_matrix[9],
+                              const double* dist_coeffs, int32_t n_dist, double* poses_dev, void* stream) {
+    if (count < 0) return fail(EKF_ERR_INVALID, "negative marker count");
+    if (count == 0) return EKF_OK;
+    if (!corners_dev || !poses_dev) return fail(EKF_ERR_INVALID, "NULL device buffer");
+    if (!(marker_size > 0.0)) return fail(EKF_ERR_INVALID, "marker_size must be > 0");
+    EkfCamera cam;
+    int rc = make_camera(camera_matrix, dist_coeffs, n_dist, &cam);
+    if (rc) return rc;
+    ekf_launch_ippe_square(corners_dev, count, marker_size, cam, poses_dev, static_cast<hipStream_t>(stream));
+    HIP_TRY(hipGetLastError());
+    return EKF_OK;
+}
+
+int ekf_estimate_poses(const double* corners, int32_t count, double marker_size, const double camera_matrix[9],
+                       const double* dist_coeffs, int32_t n_dist, double* poses, void* stream) {
+    if (count < 0) return fail(EKF_ERR_INVALID, "negative marker count");
+    if (count == 0) return EKF_OK;
+    if (!corners || !poses) return fail(EKF_ERR_INVALID, "NULL host buffer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    double* dev = nullptr;
+    HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&dev), (size_t)count * 14 * 8, s));
+    hipError_t e = hipMemcpyAsync(dev, corners, (size_t)count * 8 * 8, hipMemcpyHostToDevice, s);
+    int rc = EKF_OK;
+    if (e == hipSuccess) {
+        rc = ekf_estimate_poses_device(dev, count, marker_size, camera_matrix, dist_coeffs, n_dist, dev + (size_t)count * 8, s);
+        if (rc == EKF_OK) e = hipMemcpyAsync(poses, dev + (size_t)count * 8, (size_t)count * 6 * 8, hipMemcpyDeviceToHost, s);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFreeAsync(dev, s);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(EKF_ERR_HIP, std::string("ekf_estimate_poses: ") + hipGetErrorString(e));
+    return EKF_OK;
+}
+
 int ekf_sync(ekf_filter* f) {
     int rc = check_ready(f);
     if (rc) return rc;

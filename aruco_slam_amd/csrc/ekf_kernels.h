@@ -134,3 +134,12 @@ void ekf_launch_add_markers_rot(void* cov, int64_t ld, double* state, int32_t di
                                 const double* unc_dev, double default_unc, int32_t count, hipStream_t s);
 template <typename T>
 void ekf_launch_cov_diag(const void* cov, int64_t ld, double* out_dev, int32_t count, hipStream_t s);
+
+// Detection -> pose front end (ekf_pose_ippe.hip): pinhole camera + Brown-Conrady distortion k1 k2 p1 p2 k3 k4 k5 k6
+struct EkfCamera {
+    double fx, fy, cx, cy;
+    double k[8];
+};
+// one [tvec | rvec] per marker from its four pixel corners [count][4][2] (IPPE for a square of side marker_size)
+void ekf_launch_ippe_square(const double* corners_dev, int count, double marker_size, const EkfCamera& cam,
+                            double* poses_dev, hipStream_t s);

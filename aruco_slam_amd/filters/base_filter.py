@@ -4,10 +4,11 @@
 Only the boundary is in scope: the abstract filter API,
 the ``process_frame`` driver contract (observe only when something was
 detected, ``get_poses`` every frame -- base_filter.py:194-212) and the map file
-format (``save_map`` :214-247).  The ArUco detector / solvePnP front-end is
-OpenCV work and is not re-implemented; when ``cv2`` is importable it is used
-exactly as the reference does, otherwise frames of pre-computed detections
-are fed through ``process_detections``.
+format (``save_map`` :214-247).  The ArUco detector is OpenCV work and is not
+re-implemented (used as the reference does when ``cv2`` is importable; otherwise
+frames of pre-computed detections are fed through ``process_detections``); the
+per-marker solvePnP that follows it is one batched HIP kernel
+(``estimate_pose_of_markers``).
 """
 from __future__ import annotations
 
@@ -81,20 +82,16 @@ class BaseFilter:
         return cv2.aruco.ArucoDetector(aruco_dict, params)
 
     def estimate_pose_of_markers(self, corners, ids, marker_size):
-        """base_filter.py:92-171: IPPE-square PnP per marker -> (m,6) [tvec|rvec]."""
-        if cv2 is None:
-            raise RuntimeError("OpenCV (cv2) is not available")
-        half = marker_size / 2
-        marker_points = np.array([[-half, half, 0], [half, half, 0], [half, -half, 0],
-                                  [-half, -half, 0]], dtype=np.float32)
-        out = np.zeros((len(ids), 6))
-        for j, c in enumerate(corners):
-            _, rot, t = cv2.solvePnP(marker_points, c, self.calib_matrix, self.dist_coeffs,
-                                     rvec=None, useExtrinsicGuess=False,
-                                     flags=cv2.SOLVEPNP_IPPE_SQUARE)
-            out[j, 0:3] = t.flatten()
-            out[j, 3:6] = rot.flatten()
-        return out
+        """base_filter.py:92-171: IPPE-square PnP of every detected marker -> (m,6) [tvec|rvec].  The reference
+        loops over the markers with cv2.solvePnP(flags=SOLVEPNP_IPPE_SQUARE); here all markers of the frame go
+        through one HIP kernel (csrc/ekf_pose_ippe.hip) with the same object-point order (:113-121), camera matrix
+        and distortion coefficients.  `corners` as the detector returns them (one [1,4,2] array per marker)."""
+        if self.calib_matrix is None:
+            raise RuntimeError("no camera calibration: set calib_matrix / dist_coeffs (calibration/*.npy)")
+        from aruco_slam_amd import hip_backend
+        if len(ids) == 0:
+            return np.zeros((0, 6))
+        return hip_backend.estimate_poses(corners, marker_size, self.calib_matrix, self.dist_coeffs)
 
     def process_frame(self, frame, should_filter=True, iteration=0, marker_size=0.16):
         """base_filter.py:173-212."""

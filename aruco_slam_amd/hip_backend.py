@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = (
     "ekf_observe_sequence_device", "ekf_get_camera", "ekf_get_state", "ekf_get_cov_diag",
     "ekf_get_cov", "ekf_set_state", "ekf_set_cov", "ekf_num_landmarks", "ekf_sync",
     "ekf_set_fused", "ekf_set_kernel_timing", "ekf_get_kernel_timing", "ekf_debug_fetch",
-    "ekf_last_error_string",
+    "ekf_estimate_poses_device", "ekf_estimate_poses", "ekf_last_error_string",
 )
 
 
@@ -89,6 +89,8 @@ def load_library(path: str | Path | None = None):
         "ekf_set_kernel_timing": [vp, C.c_int32],
         "ekf_get_kernel_timing": [vp, C.c_int32, dp, C.POINTER(C.c_int64)],
         "ekf_debug_fetch": [vp, C.c_int32, dp, C.c_size_t],
+        "ekf_estimate_poses_device": [vp, C.c_int32, C.c_double, dp, dp, C.c_int32, vp, vp],
+        "ekf_estimate_poses": [dp, C.c_int32, C.c_double, dp, dp, C.c_int32, dp, vp],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)
@@ -103,6 +105,26 @@ def load_library(path: str | Path | None = None):
 
 def _dptr(a: np.ndarray):
     return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def estimate_poses(corners, marker_size: float, camera_matrix, dist_coeffs=None, device="cuda:0") -> np.ndarray:
+    """Batched IPPE-square pose of every detected marker on the GPU (ekf_estimate_poses; replaces the per-marker
+    cv2.solvePnP loop of base_filter.py:92-171).  corners: array-like [m,4,2] (or cv2's list of [1,4,2]) of pixel
+    coordinates; returns [m,6] = [tvec | rvec].  No CPU fallback."""
+    import torch
+    lib = load_library()
+    if not torch.cuda.is_available():
+        raise RuntimeError("the pose front end needs a HIP device (no CPU fallback)")
+    c = np.ascontiguousarray(np.asarray(corners, dtype=np.float64).reshape(-1, 4, 2))
+    k = np.ascontiguousarray(np.asarray(camera_matrix, dtype=np.float64).reshape(3, 3))
+    d = np.ascontiguousarray(np.asarray([] if dist_coeffs is None else dist_coeffs, dtype=np.float64).reshape(-1))
+    out = np.zeros((c.shape[0], 6))
+    with torch.cuda.device(torch.device(device)):
+        rc = lib.ekf_estimate_poses(_dptr(c), c.shape[0], float(marker_size), _dptr(k), _dptr(d) if d.size else None,
+                                    int(d.size), _dptr(out), None)
+    if rc != 0:
+        raise EkfError(rc, lib.ekf_last_error_string().decode())
+    return out
 
 
 class HipEkf:

@@ -178,6 +178,20 @@ int ekf_get_kernel_timing(ekf_filter *f, int32_t which, double *mean_us, int64_t
  * W = L^-1 H P [kpad,dims], 4 A = H (P+Q) [k,dims].  `count` = capacity of out. */
 int ekf_debug_fetch(ekf_filter *f, int32_t what, double *out, size_t count);
 
+/* Detection -> pose front end, batched (replaces the per-marker loop of cv2.solvePnP(..., SOLVEPNP_IPPE_SQUARE) in
+ * BaseFilter.estimate_pose_of_markers, filters/base_filter.py:92-171).  Stateless: no filter handle.
+ * corners [count,4,2]: pixel coordinates of each marker's corners in the detector's order (top-left, top-right,
+ * bottom-right, bottom-left = object points (-s/2, s/2), (s/2, s/2), (s/2, -s/2), (-s/2, -s/2), base_filter.py:113-121);
+ * camera_matrix: row-major 3x3 (fx, cx, fy, cy are read); dist_coeffs: n_dist <= 8 values k1 k2 p1 p2 k3 k4 k5 k6;
+ * poses [count,6] = [tvec | rvec] per marker, the layout observe() takes (base_filter.py:166-171).
+ * The `_device` form enqueues one kernel on `stream` (device pointers); the host form copies, runs and synchronises. */
+int ekf_estimate_poses_device(const double *corners_dev, int32_t count, double marker_size,
+                              const double camera_matrix[9], const double *dist_coeffs, int32_t n_dist,
+                              double *poses_dev, void *stream);
+int ekf_estimate_poses(const double *corners, int32_t count, double marker_size,
+                       const double camera_matrix[9], const double *dist_coeffs, int32_t n_dist,
+                       double *poses, void *stream);
+
 const char *ekf_last_error_string(void);
 
 #ifdef __cplusplus

@@ -67,3 +67,26 @@ def chaos_horizon(free_run, envelope=1e-8):
     d = np.abs(free_run["cam"] - free_run["cam_perturbed"]).max(axis=1)
     bad = np.nonzero(d > envelope)[0]
     return int(bad[0]) - 1 if len(bad) else len(d) - 1
+
+
+def synthetic_marker_views(count, seed=0, marker_size=0.16, width=1920, height=1080):
+    """Random marker poses in front of the reference's calibrated camera (tests/golden/calibration.npz) whose four
+    corners all fall inside the image: (camera_matrix, dist, corners_px [count,4,2], tvecs [count,3], rotations)."""
+    import numpy as np
+    from pathlib import Path
+    from scipy.spatial.transform import Rotation
+    from oracle.ippe_numpy import object_points, project_points
+    cal = np.load(Path(__file__).resolve().parent / "golden" / "calibration.npz", allow_pickle=False)
+    k, dist = cal["camera_matrix"], cal["dist_coeffs"].reshape(-1)
+    rng = np.random.default_rng(seed)
+    corners, tvecs, rots = [], [], []
+    while len(corners) < count:
+        rvec = rng.normal(size=3)
+        rvec *= rng.uniform(0.0, 1.2) / np.linalg.norm(rvec)
+        rot = Rotation.from_rotvec(rvec) * Rotation.from_euler("x", np.pi)      # marker faces the camera
+        t = np.array([rng.uniform(-1.5, 1.5), rng.uniform(-0.8, 0.8), rng.uniform(0.4, 4.0)])
+        px = project_points(object_points(marker_size) @ rot.as_matrix().T + t, k, dist)
+        if px[:, 0].min() < 0 or px[:, 0].max() > width or px[:, 1].min() < 0 or px[:, 1].max() > height:
+            continue
+        corners.append(px); tvecs.append(t); rots.append(rot)
+    return k, dist, np.stack(corners), np.stack(tvecs), rots

@@ -154,7 +154,20 @@ def golden_rotations_app_loop(traj_writer_cls):
 C1_SEED = 6
 
 
+def golden_calibration():
+    """The reference's own camera calibration (calibration/camera_matrix.npy, dist_coeffs.npy: plain numeric
+    arrays, loaded without pickle) as a fixture for the detection -> pose tests."""
+    ref = Path("/root/reference/calibration")
+    k = np.load(ref / "camera_matrix.npy", allow_pickle=False)
+    d = np.load(ref / "dist_coeffs.npy", allow_pickle=False)
+    np.savez(HERE / "calibration.npz", camera_matrix=k, dist_coeffs=d)
+    print("calibration.npz", k.shape, d.shape)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "calib":
+        golden_calibration()
+        return
     ekf_cls, traj_writer_cls = load_reference()
     if len(sys.argv) > 1 and sys.argv[1] == "g5":
         golden_rotations()

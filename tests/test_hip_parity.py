@@ -877,3 +877,36 @@ def test_map_file_restore_on_the_hip_filter_vs_oracle(golden_dir):
         if steps == 5:
             break
     assert flt.num_landmarks == orc.num_landmarks == len(g["lm_ids"]) + 1
+
+
+@pytest.mark.gpu
+def test_pose_front_end_kernel_vs_oracle_and_projected_poses():
+    """f3: ekf_estimate_poses (batched IPPE-square, csrc/ekf_pose_ippe.hip) against the NumPy restatement
+    (oracle/ippe_numpy.py) on the same corners, and against the poses the corners were projected from through the
+    reference's calibrated camera (tests/golden/calibration.npz).  Parity unpinned: no OpenCV here, no fixture of
+    the reference covers cv2.solvePnP (base_filter.py:157-165)."""
+    from scipy.spatial.transform import Rotation
+    from aruco_slam_amd import hip_backend
+    from aruco_slam_amd.filters.base_filter import BaseFilter
+    from conftest import synthetic_marker_views
+    from oracle.ippe_numpy import estimate_pose_of_markers
+    k, dist, corners, tvecs, rots = synthetic_marker_views(500, seed=2)
+    got = hip_backend.estimate_poses(corners, 0.16, k, dist)
+    want = estimate_pose_of_markers(corners, 0.16, k, dist)
+    assert got.shape == (500, 6) and np.isfinite(got).all()
+    assert np.abs(got[:, :3] - want[:, :3]).max() <= 1e-9
+    for j in range(len(corners)):
+        assert np.abs((Rotation.from_rotvec(got[j, 3:]) * Rotation.from_rotvec(want[j, 3:]).inv()).as_rotvec()).max() <= 1e-9
+        assert np.abs(got[j, :3] - tvecs[j]).max() <= 5e-5 * np.linalg.norm(tvecs[j])
+        assert np.abs((Rotation.from_rotvec(got[j, 3:]) * rots[j].inv()).as_rotvec()).max() <= 5e-5
+    # through the filter boundary, with corners as cv2's detector returns them (one float32 [1,4,2] array per marker)
+    flt = BaseFilter.__new__(BaseFilter)
+    flt.calib_matrix, flt.dist_coeffs = k, dist.reshape(1, -1)
+    cv_corners = [c.astype(np.float32).reshape(1, 4, 2) for c in corners[:7]]
+    poses = flt.estimate_pose_of_markers(cv_corners, np.arange(7), 0.16)
+    ref32 = estimate_pose_of_markers(np.stack(cv_corners).astype(np.float64), 0.16, k, dist)
+    assert poses.shape == (7, 6) and np.abs(poses - ref32).max() <= 1e-8
+    assert flt.estimate_pose_of_markers([], np.arange(0), 0.16).shape == (0, 6)
+    with pytest.raises(hip_backend.EkfError) as e:
+        hip_backend.estimate_poses(corners[:2], 0.16, k, np.zeros(9))          # 9 distortion coefficients
+    assert e.value.code == -1

@@ -257,3 +257,23 @@ def test_hand_issued_loads_are_not_touched_before_their_wait(tmp_path):
         if "cov_update" in out.name:
             assert n_loads >= 1000, (out.name, n_loads)      # the f32 covariance update's operand ring
         assert not hazards, (out.name, hazards[:3])
+
+
+def test_ippe_oracle_recovers_the_poses_its_corners_were_projected_from():
+    """oracle/ippe_numpy.py (restatement of cv2.solvePnP(..., SOLVEPNP_IPPE_SQUARE), base_filter.py:92-171; parity
+    unpinned: OpenCV is not available and the reference holds no corner / pose pairs): markers projected through
+    the reference's calibrated camera model come back with their pose.  The bound is the residual of the 5-iteration
+    undistortion at the image border (measured 1.1e-5), not of the pose algebra (1e-12 without distortion)."""
+    from scipy.spatial.transform import Rotation
+    from conftest import synthetic_marker_views
+    from oracle.ippe_numpy import estimate_pose_of_markers, ippe_square, object_points, project_points
+    k, dist, corners, tvecs, rots = synthetic_marker_views(300, seed=1)
+    poses = estimate_pose_of_markers(corners, 0.16, k, dist)
+    for j in range(len(corners)):
+        assert np.abs(poses[j, :3] - tvecs[j]).max() <= 5e-5 * np.linalg.norm(tvecs[j])
+        assert np.abs((Rotation.from_rotvec(poses[j, 3:]) * rots[j].inv()).as_rotvec()).max() <= 5e-5
+    # without distortion the pose algebra is exact to rounding, and the second candidate has the larger error
+    px = project_points(object_points(0.16) @ rots[0].as_matrix().T + tvecs[0], k, None)
+    t, r, sols = ippe_square(px, 0.16, k, None)
+    assert np.abs(t - tvecs[0]).max() <= 1e-10 and sols[0][2] <= sols[1][2]
+    assert np.abs((Rotation.from_rotvec(r) * rots[0].inv()).as_rotvec()).max() <= 1e-9
