@@ -77,7 +77,7 @@ Layout make_layout(const ekf_config& c) {
     // pipelined sequence mode (f32 covariance, MFMA update, fused front kernel): the second covariance buffer
     // (P_t is read, P_{t+1} written elsewhere, so that the next front kernel can read P_t beside the update)
     L.has_cov2 = c.cov_dtype == EKF_COV_F32 && c.cov_kernel != EKF_COVK_VALU && (c.flags & 5) == 0 &&
-                 ((c.flags & 2) != 0 || L.cap >= 2400);
+                 ((c.flags & 2) != 0 || L.cap >= 640);
     L.off_cov2 = L.has_cov2 ? take((size_t)L.cap * L.cap * L.elem) : 0;
     L.off_wdbg = take((size_t)L.kmax * L.cap * 8);
     L.off_idx = take((size_t)c.max_visible * 4);
@@ -581,12 +581,13 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
     // Pipelined mode (F(t+1) beside C(t), see below): flags bit 1 forces it, bit 0 forbids it, otherwise it is
     // chosen where it was measured to win (tools/pipeline_sweep.py).  f32 covariance with the MFMA update and the
     // fused front kernel only.
-    // (tools/pipeline_sweep.py, us per frame pipelined / serial: n=512 m=32 31.7 / 30.8 - n=1024 m=32 31.8 / 38.3 -
-    // n=1024 m=64 142.8 / 135.2 - n=2048 m=32 63.3 / 72.5 - n=2048 m=64 163.4 / 188.9 - n=4096 m=32 238.8 / 249.6 -
-    // n=4096 m=64 561.7 / 444.5)
+    // (tools/pipeline_sweep.py, us per frame pipelined / serial: n=256 m=16 16.8 / 20.3 - n=512 m=16 21.1 / 21.1 -
+    // n=512 m=32 25.9 / 30.6 - n=1024 m=32 27.8 / 38.6 - n=1024 m=64 115 / 133 - n=2048 m=32 62.8 / 72.9 -
+    // n=2048 m=64 134 / 187 - n=3072 m=64 247 / 298 - n=4096 m=32 240 / 247 - n=4096 m=64 474 / 443: there the front
+    // kernel's 273 workgroups hold every CU while they wait for the factorisation, and the update cannot run beside them)
     const int dims_now = f->dims();
     const int kpad_now = (int)round_up(f->lay.rd * m, EKF_RB);
-    const bool auto_on = kpad_now <= 96 ? dims_now >= 2400 : (dims_now >= 4800 && dims_now <= 9000);
+    const bool auto_on = dims_now >= 700 && !(dims_now > 9000 && kpad_now > 96);
     const bool want = (f->cfg.flags & 2) != 0 || ((f->cfg.flags & 1) == 0 && auto_on);
     bool pipelined = want && f->lay.has_cov2 && !f->timing && frames >= 2 && (f->cfg.flags & 4) == 0;
     if (pipelined && f->la_ok < 0) {
@@ -645,10 +646,6 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
     static const char* la_env = getenv("EKF_LA_LDS_KB");          // (experiments)
     const int nb_now = (int)round_up(L.rd * m, EKF_RB) / EKF_RB;
     const int grid_now = nb_now * (nb_now + 1) / 2 + 2 + (int)round_up(f->dims(), 128) / 64;
-    static const char* wpe_env = getenv("EKF_PIPE_WPE");          // (experiments) occupancy of the update beside the front kernel
-    const int pipe_variant = wpe_env ? 10 + atoi(wpe_env) : 2;
-    static const char* late_env = getenv("EKF_LA_LATE");          // (experiments)
-    const int la_late = late_env ? atoi(late_env) : 0;
     const int la_lds = la_env ? atoi(la_env) * 1024 : (grid_now <= 100 ? 148 * 1024 : 0);
     // (stream B needs no edge from stream A at the start: its first launch is the gate in front of C(0), which waits
     // for "F(1) has started", i.e. for everything that is on stream A now and F(0); the previous call ended with
@@ -668,7 +665,6 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
         fr.la_signal = (t > 0) ? base + (uint64_t)t : 0;       // "F(t) has started": F(t-1) is complete
         fr.la_gate = (t > 0) ? base + (uint64_t)t : 0;         // C(t-1) complete before F(t) ends
         fr.lds_min = la_lds;
-        fr.la_late = la_late;
         if (t + 1 < frames) {                                  // the next frame's detections: its support columns of W_t
             fr.next_idx = lm_index_dev + (size_t)(t + 1) * m;
             fr.next_m = m;
@@ -681,7 +677,7 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
         EkfFrame cf = fr;
         cf.cov = cbuf[par];
         cf.cov_out = cbuf[par ^ 1];
-        ekf_launch_cov_update<float>(cf, pipe_variant, f->big);
+        ekf_launch_cov_update<float>(cf, 2, f->big);
         // an odd number of frames leaves the covariance in the internal buffer: back into the caller's
         if (t + 1 == frames && (frames & 1))
             HIP_TRY(hipMemcpyAsync(f->cov, cbuf[1], (size_t)L.cap * L.cap * L.elem, hipMemcpyDeviceToDevice, f->big));

@@ -404,14 +404,6 @@ void ekf_launch_cov_update<float>(const EkfFrame& fr, int variant, hipStream_t s
     } else {
         const int items = ekf_tri_items(fr);
         const dim3 grid((items + 3) / 4), block(256);
-        if (variant >= 10 && fr.kpad == 96) {      // (experiments: occupancy of the update in the pipelined mode)
-            switch (variant - 10) {
-                case 2: EKF_COV_LAUNCH((ekf_cov_update_mfma_f32<6, 3, 2>), grid, block, s, e0, e1, fr, items); return;
-                case 3: EKF_COV_LAUNCH((ekf_cov_update_mfma_f32<6, 3, 3>), grid, block, s, e0, e1, fr, items); return;
-                case 4: EKF_COV_LAUNCH((ekf_cov_update_mfma_f32<6, 3, 4>), grid, block, s, e0, e1, fr, items); return;
-                default: break;
-            }
-        }
         switch (fr.kpad / 16) {
             // The kernel counts its own loads (s_waitcnt by hand), so it must not spill: 5 waves per SIMD
             // (96 registers) up to k = 128, 4 waves (128 registers) above, where hipcc needs a few more

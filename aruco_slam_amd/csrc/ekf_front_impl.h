@@ -8,14 +8,19 @@
 // the dispatcher starts first, so the waits cannot deadlock whatever the residency):
 //   0              measurement model: Jacobian rows / residual for the other roles
 //   [1, nS]        one 16x16 block of S each, straight from P (nS = nb (nb+1) / 2)
-//   nS + 1         the factorisation: streams the S blocks into LDS as they appear, runs the
+//   nS + 1         the factorisation: takes the S blocks into registers as they appear, runs the
 //                  pivot chain, publishes -L / Dinv / y block column by block column
 //   > nS + 1       one chunk of 64 columns each: A chunk into LDS, then the right-looking blocked
 //                  forward substitution in registers, consuming block column q of the factor as soon
-//                  as it is published; W chunk, dx chunk, state injection for its own columns (the
-//                  only readers of the old state are workgroups 0 .. nS, which the factorisation has
-//                  waited for).  EKF_Rotations: the LAST chunk to finish injects (every landmark
-//                  carries a quaternion that straddles chunks).
+//                  as it is published (requested one step ahead); W chunk, dx chunk, state injection
+//                  for its own columns (the only readers of the old state are workgroups 0 .. nS, which
+//                  the factorisation has waited for).  EKF_Rotations: the LAST chunk to finish injects
+//                  (every landmark carries a quaternion that straddles chunks).
+// Pipelined sequence mode (ekf_api.hip: ekf_observe_sequence_device): the launch runs BESIDE the covariance
+// update of the previous frame, on the previous frame's input P: the S-block and chunk roles complete the
+// entries of the current P they read from (P_prev, W_prev) themselves, with the covariance update's own
+// per-element instruction sequence (same bits); the chunks leave the support columns of W the NEXT frame
+// will need for that in a compact copy (W_sup).
 // Exchange between workgroups: ekf_solve_device.h (agent-scope relaxed accesses: write-through
 // stores, coherent loads, sentinel values; no flags, no global fences, no cache flushes).  The
 // protocol needs exactly one hardware property, per-location coherence of agent-scope atomics:
@@ -121,11 +126,7 @@ __device__ __forceinline__ void fr_role_sblock(const EkfFrame& fr, int sb, int n
     // The sums run on the matrix cores (v_mfma_f32_32x32x2_f32 over k ascending, as in the covariance update), one
     // wave per 32 x 32 tile of [row slots] x [column slots] -- the LAST waves of the workgroup, beside the index ->
     // P round trips and the measurement model of the others; their operand loads do not depend on the indices.
-#ifdef FR_NOFIX_S
-    const bool fix = false;
-#else
     const bool fix = sizeof(T) == 4 && fr.wsup_prev != nullptr;
-#endif
     constexpr int NT = (NSLOT + 31) / 32, DLD = 32 * NT, DR = NB < FR_DOT_RING ? NB : FR_DOT_RING;
     float* dots = reinterpret_cast<float*>(rsd + fr.kpad);    // [32 NT][32 NT]
     const int dlane = tid & 63, dl31 = dlane & 31, dlhi = dlane >> 5, dtile = 7 - (tid >> 6);
@@ -285,7 +286,7 @@ __device__ __forceinline__ void fr_role_measure(const EkfFrame& fr, double* sm) 
     int* lmc = reinterpret_cast<int*>(rsd + fr.kpad);
     const int tid = threadIdx.x;
     // pipelined sequence mode: this launch has started, i.e. everything before it on its stream is complete
-    if (fr.la_signal && !fr.la_late && tid == 0)
+    if (fr.la_signal && tid == 0)
         __hip_atomic_store(fr.la_sync, fr.la_signal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     double cam[EKF_CAM];
 #pragma unroll
@@ -412,8 +413,6 @@ struct SvIoFused {
                 settle_block(z1[tc], i1, tc, lane);
                 stale |= fr_tag_stale(t1[tc], fr.seqno);
             }
-        if (C0 == 0 && fr.la_signal && fr.la_late && threadIdx.x == 0)
-            __hip_atomic_store(fr.la_sync, fr.la_signal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         // the residual row (one wave): z - h, replicated in all 16 rows of its "block".  All loads first, THEN the
         // sentinel checks (one round trip)
         if (res0) {
@@ -520,9 +519,9 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
     const double* __restrict__ xy = fr.xl + fr.xl_y;
     long long* stp = (fr.stamps && col0 == 0 && lane == 0) ? fr.stamps + 34 : nullptr;
     T* __restrict__ wp = static_cast<T*>(fr.wpanel);
-    // pipelined sequence mode: the columns of W that the NEXT frame's priority rows need (its support rows:
-    // camera + every next-frame detection's landmark) are also written compactly, W_sup[k][slot], so that the
-    // priority-row kernel reads its A operand coalesced instead of gathering 96 x 106 scattered words per tile.
+    // pipelined sequence mode: the columns of W that the NEXT frame's front kernel needs for its support rows
+    // (camera + every next-frame detection's landmark) are also written compactly, W_sup[k][slot], so that it
+    // stages them with 16-byte loads instead of gathering 96 x 106 scattered words.
     // smask: next-frame detections whose landmark owns this lane's column (duplicates possible); cslot: camera slot
     T* __restrict__ wsup = static_cast<T*>(fr.wsup);
     const unsigned long long smask = pre.smask;
@@ -728,11 +727,7 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
     constexpr int NWV = FR_T / 64;
     double* hs = sm;                                    // [k][JC]
     double* a_lds = sm + fr.k * JC;                     // [kpad][FR_ALD]; before A is built: the support-row tiles (pipelined mode)
-#ifdef FR_NOFIX_C
-    const bool fix = false;
-#else
     const bool fix = sizeof(T) == 4 && fr.wprev != nullptr;
-#endif
     const size_t a_len = fr_chunk_a_len(fr.kpad, fix);
     int* lmc = reinterpret_cast<int*>(a_lds + a_len);
     int* flag = lmc + 64;                               // [0] last-chunk flag, [1..2] panel sync words

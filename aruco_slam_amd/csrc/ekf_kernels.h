@@ -70,7 +70,6 @@ struct EkfFrame {
     // finish before [1] >= la_gate (0 = no gate).
     unsigned long long* la_sync;
     unsigned long long la_signal, la_gate;
-    int32_t la_late;           // 1: la_signal is stored once the S blocks are in the factorisation's registers instead of at the start
     int32_t lds_min;           // front kernel: claim at least this much LDS (keeps other kernels' workgroups off its CUs)
     void* wsup;                // pipelined mode, written by the chunks: W[:, support rows of the NEXT frame], [kpad][wsup_ld] in cov dtype (null: none)
     int32_t wsup_ld;

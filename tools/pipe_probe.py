@@ -1,5 +1,5 @@
 """Diagnostics: us per frame of the pipelined sequence mode at one shape, for the environment it is started in
-(EKF_LA_LATE, EKF_PIPE_WPE, EKF_LA_LDS_KB are read once per process):  python tools/pipe_probe.py [n m frames]"""
+(EKF_LA_LDS_KB is read once per process):  python tools/pipe_probe.py [n m frames]"""
 import sys, time, os
 import numpy as np, torch
 sys.path.insert(0, ".")
