@@ -74,9 +74,9 @@ Layout make_layout(const ekf_config& c) {
     }
     L.off_wpanel = take((size_t)L.kmax * L.cap * L.elem);
     L.off_wpanel2 = take((size_t)L.kmax * L.cap * L.elem);
-    // pipelined sequence mode (f32 covariance, MFMA update, fused front kernel): the second covariance buffer
+    // pipelined sequence mode (MFMA update, fused front kernel): the second covariance buffer
     // (P_t is read, P_{t+1} written elsewhere, so that the next front kernel can read P_t beside the update)
-    L.has_cov2 = c.cov_dtype == EKF_COV_F32 && c.cov_kernel != EKF_COVK_VALU && (c.flags & 5) == 0 &&
+    L.has_cov2 = c.cov_kernel != EKF_COVK_VALU && (c.flags & 5) == 0 &&
                  ((c.flags & 2) != 0 || L.cap >= 640);
     L.off_cov2 = L.has_cov2 ? take((size_t)L.cap * L.cap * L.elem) : 0;
     L.off_wdbg = take((size_t)L.kmax * L.cap * 8);
@@ -579,7 +579,7 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
     if (!lm_index_dev || !z_dev) return fail(EKF_ERR_INVALID, "NULL detections");
     if (f->n_lm < 1) return fail(EKF_ERR_STATE, "observe before any landmark was added");
     // Pipelined mode (F(t+1) beside C(t), see below): flags bit 1 forces it, bit 0 forbids it, otherwise it is
-    // chosen where it was measured to win (tools/pipeline_sweep.py).  f32 covariance with the MFMA update and the
+    // chosen where it was measured to win (tools/pipeline_sweep.py).  MFMA covariance update (f32 or f64) and the
     // fused front kernel only.
     // (tools/pipeline_sweep.py, us per frame pipelined / serial: n=256 m=16 16.8 / 20.3 - n=512 m=16 21.1 / 21.1 -
     // n=512 m=32 25.9 / 30.6 - n=1024 m=32 27.8 / 38.6 - n=1024 m=64 115 / 133 - n=2048 m=32 62.8 / 72.9 -
@@ -671,13 +671,13 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
             fr.wsup = wsup[par];
         }
         bind_exchange(f, fr);
-        ekf_launch_front<float>(fr, f->stream);
+        if (L.elem == 4) ekf_launch_front<float>(fr, f->stream); else ekf_launch_front<double>(fr, f->stream);
         if (t + 1 == frames) ekf_launch_signal(sync, base + (uint64_t)frames, f->stream);     // no F(t+1) to say that F(t) is over
         ekf_launch_gate(sync, base + (uint64_t)t + 1, status, f->big);
         EkfFrame cf = fr;
         cf.cov = cbuf[par];
         cf.cov_out = cbuf[par ^ 1];
-        ekf_launch_cov_update<float>(cf, 2, f->big);
+        if (L.elem == 4) ekf_launch_cov_update<float>(cf, 2, f->big); else ekf_launch_cov_update<double>(cf, 2, f->big);
         // an odd number of frames leaves the covariance in the internal buffer: back into the caller's
         if (t + 1 == frames && (frames & 1))
             HIP_TRY(hipMemcpyAsync(f->cov, cbuf[1], (size_t)L.cap * L.cap * L.elem, hipMemcpyDeviceToDevice, f->big));

@@ -246,7 +246,8 @@ __global__ __launch_bounds__(256) void ekf_cov_update_mfma_f64(EkfFrame fr, int 
     ekf_tri_decode(item, I, J);
     const int i0 = 32 * I, j0 = 32 * J;
     const double* __restrict__ wp = static_cast<const double*>(fr.wpanel);
-    double* __restrict__ P = static_cast<double*>(fr.cov);
+    const double* P = static_cast<const double*>(fr.cov);      // (pipelined sequence mode: P_t in, P_{t+1} out elsewhere)
+    double* Pout = fr.cov_out ? static_cast<double*>(fr.cov_out) : static_cast<double*>(fr.cov);
     const int64_t ld = fr.ld, ldw = fr.ldw;
 
     // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 reg
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(256) void ekf_cov_update_mfma_f64(EkfFrame fr, int 
                 double v = pt[ri][ci][r];
                 if (I == J && rl == cl) v += ekf_qdiag(i0 + rl, fr.dims, fr.nz);
                 v += acc[ri][ci][r];
-                ekf_cov_store(P + (int64_t)(i0 + rl) * ld + j0 + cl, v);
+                ekf_cov_store(Pout + (int64_t)(i0 + rl) * ld + j0 + cl, v);
                 if (I != J) tr[wave][rl][cl] = v;
             }
     if (I != J) {
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(256) void ekf_cov_update_mfma_f64(EkfFrame fr, int 
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int cc = 2 * it + lhi;
-            ekf_cov_store(P + (int64_t)(j0 + cc) * ld + i0 + l31, tr[wave][l31][cc]);
+            ekf_cov_store(Pout + (int64_t)(j0 + cc) * ld + i0 + l31, tr[wave][l31][cc]);
         }
     }
 }
@@ -326,7 +327,8 @@ __global__ __launch_bounds__(256) void ekf_cov_update_mfma_f64_split(EkfFrame fr
     ekf_tri_decode(blockIdx.x, I, J);
     const int i0 = 32 * I, j0 = 32 * J;
     const double* __restrict__ wp = static_cast<const double*>(fr.wpanel);
-    double* __restrict__ P = static_cast<double*>(fr.cov);
+    const double* P = static_cast<const double*>(fr.cov);
+    double* Pout = fr.cov_out ? static_cast<double*>(fr.cov_out) : static_cast<double*>(fr.cov);
     const int64_t ld = fr.ld, ldw = fr.ldw;
     double pt[4];
 #pragma unroll
@@ -352,14 +354,14 @@ __global__ __launch_bounds__(256) void ekf_cov_update_mfma_f64_split(EkfFrame fr
         double v = pt[r];
         if (I == J && rl == cl) v += ekf_qdiag(i0 + rl, fr.dims, fr.nz);
         v += acc[r];
-        ekf_cov_store(P + (int64_t)(i0 + rl) * ld + j0 + cl, v);
+        ekf_cov_store(Pout + (int64_t)(i0 + rl) * ld + j0 + cl, v);
         if (I != J) tr[rl][cl] = v;
     }
     if (I != J) {
         __syncthreads();
         const int l31 = threadIdx.x & 31;
         for (int cc = threadIdx.x >> 5; cc < 32; cc += 8)          // column cc of D = row of D^T
-            ekf_cov_store(P + (int64_t)(j0 + cc) * ld + i0 + l31, tr[l31][cc]);
+            ekf_cov_store(Pout + (int64_t)(j0 + cc) * ld + i0 + l31, tr[l31][cc]);
     }
 }
 

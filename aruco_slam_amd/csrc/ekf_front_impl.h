@@ -53,8 +53,11 @@
 // doubles of the chunk role's A region (pipelined mode: before A is built the region holds the staged operands of
 // the support-row product, W_sup [96][128] and W [96][64], and its result [128][64], all f32: 104 KB)
 #define FR_KS 96            // rows of W staged at a time
-__host__ __device__ inline size_t fr_chunk_a_len(int kpad, bool fix) {
-    const size_t a = (size_t)kpad * FR_ALD, st = (size_t)(FR_KS * 128 + FR_KS * 64 + 128 * 64) / 2;
+// (f64 covariance: 48 rows of W at a time and 64 slots per round: [48][64] + [48][64] + [64][64] doubles, 80 KB)
+#define FR_KS64 48
+__host__ __device__ inline size_t fr_chunk_a_len(int kpad, bool fix, int elem) {
+    const size_t a = (size_t)kpad * FR_ALD;
+    const size_t st = elem == 4 ? (size_t)(FR_KS * 128 + FR_KS * 64 + 128 * 64) / 2 : (size_t)(2 * FR_KS64 * 64 + 64 * 64);
     return (fix && a < st) ? st : a;
 }
 
@@ -126,11 +129,14 @@ __device__ __forceinline__ void fr_role_sblock(const EkfFrame& fr, int sb, int n
     // The sums run on the matrix cores (v_mfma_f32_32x32x2_f32 over k ascending, as in the covariance update), one
     // wave per 32 x 32 tile of [row slots] x [column slots] -- the LAST waves of the workgroup, beside the index ->
     // P round trips and the measurement model of the others; their operand loads do not depend on the indices.
-    const bool fix = sizeof(T) == 4 && fr.wsup_prev != nullptr;
+    // (f64 covariance: the same with v_mfma_f64_16x16x4_f64 on 16 x 16 tiles, the f64 update's sequence.)
+    const bool fix = fr.wsup_prev != nullptr;
     constexpr int NT = (NSLOT + 31) / 32, DLD = 32 * NT, DR = NB < FR_DOT_RING ? NB : FR_DOT_RING;
+    constexpr int NT16 = (NSLOT + 15) / 16, DLD64 = 16 * NT16;
+    double* dots64 = rsd + fr.kpad;                           // [16 NT16][16 NT16] (f64 covariance)
     float* dots = reinterpret_cast<float*>(rsd + fr.kpad);    // [32 NT][32 NT]
     const int dlane = tid & 63, dl31 = dlane & 31, dlhi = dlane >> 5, dtile = 7 - (tid >> 6);
-    const bool dotw = fix && dtile < NT * NT;
+    const bool dotw = sizeof(T) == 4 && fix && dtile < NT * NT;
     float ra[DR][8], rb[DR][8];
     const float* __restrict__ wsd = static_cast<const float*>(fr.wsup_prev);
     unsigned aoff = 0, boff = 0;
@@ -201,6 +207,33 @@ __device__ __forceinline__ void fr_role_sblock(const EkfFrame& fr, int sb, int n
         for (int reg = 0; reg < 16; ++reg)
             dots[(32 * (dtile / NT) + (reg & 3) + 8 * (reg >> 2) + 4 * dlhi) * DLD + 32 * (dtile % NT) + dl31] = dacc[reg];
     }
+    if constexpr (sizeof(T) == 8) {
+        if (fix) {      // f64: 16 x 16 tiles, the last waves first; A[i = c][k = g] = -W_sup[4 s + g][row slot], B[k = g][j = c]
+            const double* __restrict__ w64 = static_cast<const double*>(fr.wsup_prev);
+            const int dc = dlane & 15, dg = dlane >> 4, smax = fr.wsup_ld - 1;
+            for (int tile = dtile; tile < NT16 * NT16; tile += 8) {
+                const int rs = 16 * (tile / NT16) + dc, cs = 16 * (tile % NT16) + dc;
+                const int gr = (rs < EKF_CAM) ? rs : min(EKF_CAM + LMD * j0 + (rs - EKF_CAM), smax);
+                const int gc = (cs < EKF_CAM) ? cs : min(EKF_CAM + LMD * jc0 + (cs - EKF_CAM), smax);
+                const double* wa = w64 + (int64_t)dg * fr.wsup_ld + gr;
+                const double* wb = w64 + (int64_t)dg * fr.wsup_ld + gc;
+                pf64x4 dacc = {0.0, 0.0, 0.0, 0.0};
+                for (int ks = 0; ks < (fr.kpad >> 2); ks += 4) {
+                    double a[4], b[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        a[u] = wa[(int64_t)(4 * (ks + u)) * fr.wsup_ld];
+                        b[u] = wb[(int64_t)(4 * (ks + u)) * fr.wsup_ld];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) dacc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[u], b[u], dacc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)      // C / D layout: column c, row g + 4 r
+                    dots64[(16 * (tile / NT16) + dg + 4 * r) * DLD64 + 16 * (tile % NT16) + dc] = dacc[r];
+            }
+        }
+    }
     fr_measure<MODEL>(fr, cam, lmc, hs, rsd, tid, false);
     __syncthreads();
     if (fix) {
@@ -213,8 +246,14 @@ __device__ __forceinline__ void fr_role_sblock(const EkfFrame& fr, int sb, int n
                 for (int b = 0; b < JC; ++b) {
                     const int col = (b < EKF_CAM) ? b : uc20[n] + (b - EKF_CAM);
                     const int cs = (b < EKF_CAM) ? b : cdet + (b - EKF_CAM);
-                    const float q = (col == urho[n]) ? (float)ekf_qdiag(urho[n], fr.dims, fr.nz) : 0.0f;
-                    pv[n][b] = (T)(((float)pv[n][b] + q) + dots[uslot * DLD + cs]);
+                    if constexpr (sizeof(T) == 4) {
+                        const float q = (col == urho[n]) ? (float)ekf_qdiag(urho[n], fr.dims, fr.nz) : 0.0f;
+                        pv[n][b] = (T)(((float)pv[n][b] + q) + dots[uslot * DLD + cs]);
+                    } else {      // (the f64 update: v = P; if (diagonal) v += Q; v += acc)
+                        double v = (double)pv[n][b];
+                        if (col == urho[n]) v += ekf_qdiag(urho[n], fr.dims, fr.nz);
+                        pv[n][b] = (T)(v + dots64[uslot * DLD64 + cs]);
+                    }
                 }
             }
         }
@@ -727,8 +766,8 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
     constexpr int NWV = FR_T / 64;
     double* hs = sm;                                    // [k][JC]
     double* a_lds = sm + fr.k * JC;                     // [kpad][FR_ALD]; before A is built: the support-row tiles (pipelined mode)
-    const bool fix = sizeof(T) == 4 && fr.wprev != nullptr;
-    const size_t a_len = fr_chunk_a_len(fr.kpad, fix);
+    const bool fix = fr.wprev != nullptr;
+    const size_t a_len = fr_chunk_a_len(fr.kpad, fix, (int)sizeof(T));
     int* lmc = reinterpret_cast<int*>(a_lds + a_len);
     int* flag = lmc + 64;                               // [0] last-chunk flag, [1..2] panel sync words
     double* pshare = reinterpret_cast<double*>(lmc + 72);   // [8][64] Dinv operands and y of one block column
@@ -904,6 +943,92 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
             }
             __syncthreads();
         }
+    } else {
+        // f64 covariance: the same on v_mfma_f64_16x16x4_f64 (the f64 update's per-element sequence: v = P; on the
+        // diagonal v += Q; v += acc), 64 slots per round: wave g computes the 16-slot tile row g / 2 for the
+        // column tiles 2 (g & 1) and 2 (g & 1) + 1; W staged 48 rows at a time.
+        typedef double fr_d2 __attribute__((ext_vector_type(2)));
+        double* sA = a_lds;                           // [FR_KS64][64]
+        double* sB = sA + FR_KS64 * 64;               // [FR_KS64][64]
+        double* pl = sB + FR_KS64 * 64;               // [64][64]
+        const double* __restrict__ wsa = static_cast<const double*>(fr.wsup_prev);
+        const double* __restrict__ wpb = static_cast<const double*>(fr.wprev);
+        const double* __restrict__ Pd = static_cast<const double*>(fr.cov);
+        const int nslots = EKF_CAM + LMD * m;
+        const int lane = tid & 63, lc = lane & 15, lg = lane >> 4;
+        const int trow = g >> 1, ct0 = 2 * (g & 1);
+        for (int round = 0; 64 * round < nslots; ++round) {
+            const bool tile_ok = 64 * round + 16 * trow < nslots;
+            pf64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+            double pt[2][4];
+            int prw[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int slot = 64 * round + 16 * trow + lg + 4 * r;
+                const int sj = min(max((slot - EKF_CAM) / LMD, 0), m - 1);
+                prw[r] = (slot < EKF_CAM) ? slot : (slot < nslots ? lmc[sj] + (slot - EKF_CAM) % LMD : 0);
+            }
+            for (int kb0 = 0; kb0 < fr.kpad; kb0 += FR_KS64) {
+                constexpr int NL = FR_KS64 * 32 / FR_T;         // 16-byte loads per thread and operand
+                const int rows = min(FR_KS64, fr.kpad - kb0);
+                fr_d2 va[NL], vb[NL];
+#pragma unroll
+                for (int n = 0; n < NL; ++n) {
+                    const int e = tid + FR_T * n, row = min(e >> 5, rows - 1), c2 = e & 31;
+                    const int col = min(64 * round + 2 * c2, fr.wsup_ld - 2);
+                    va[n] = *reinterpret_cast<const fr_d2*>(wsa + (int64_t)(kb0 + row) * fr.wsup_ld + col);
+                    vb[n] = *reinterpret_cast<const fr_d2*>(wpb + (int64_t)(kb0 + row) * fr.ldw + chunk0 + 2 * c2);
+                }
+                if (kb0 == 0 && tile_ok) {
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pt[t2][r] = Pd[(int64_t)prw[r] * ld + chunk0 + 16 * (ct0 + t2) + lc];
+                }
+                if (kb0 == 0 && round == 0) fetch_jacobian();
+                if (kb0 > 0) __syncthreads();
+#pragma unroll
+                for (int n = 0; n < NL; ++n) {
+                    *reinterpret_cast<fr_d2*>(sA + 2 * (tid + FR_T * n)) = va[n];
+                    *reinterpret_cast<fr_d2*>(sB + 2 * (tid + FR_T * n)) = vb[n];
+                }
+                __syncthreads();
+                if (tile_ok) {
+                    for (int s4 = 0; s4 < (rows >> 2); ++s4) {      // A[i = c][k = g], B[k = g][j = c]
+                        const double a = -sA[(4 * s4 + lg) * 64 + 16 * trow + lc];
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sB[(4 * s4 + lg) * 64 + 16 * ct0 + lc], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sB[(4 * s4 + lg) * 64 + 16 * ct0 + 16 + lc], acc1, 0, 0, 0);
+                    }
+                }
+            }
+            if (tile_ok) {
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {      // C / D layout: column c, row g + 4 r
+                        const int colg = chunk0 + 16 * (ct0 + t2) + lc;
+                        double v = pt[t2][r];
+                        if (prw[r] == colg) v += ekf_qdiag(prw[r], fr.dims, fr.nz);
+                        v += t2 ? acc1[r] : acc0[r];
+                        pl[(16 * trow + lg + 4 * r) * 64 + 16 * (ct0 + t2) + lc] = v;
+                    }
+            }
+            __syncthreads();
+            if (round == 0) {
+#pragma unroll
+                for (int a = 0; a < EKF_CAM; ++a) pcr[a] = (T)pl[a * 64 + cl];
+            }
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int ju = min(g + NWV * u, m - 1);
+#pragma unroll
+                for (int d = 0; d < LMD; ++d) {
+                    const int slot = EKF_CAM + LMD * ju + d;
+                    if ((slot >> 6) == round) plr[u][d] = (T)pl[(slot & 63) * 64 + cl];
+                }
+            }
+            __syncthreads();
+        }
     }
     if (!fix) fetch_jacobian();
     __syncthreads();
@@ -1015,10 +1140,11 @@ static void ekf_front_go(const EkfFrame& fr, hipStream_t s) {
         once = true;
     }
     const int nb = fr.kpad / EKF_RB, nS = nb * (nb + 1) / 2;
-    const bool fix = sizeof(T) == 4 && fr.wprev != nullptr;
-    const size_t lds_s = ((size_t)fr.k * JC + NSLOT * 16 + 32 + fr.kpad) * 8 + 16 +
-                         (fix ? (size_t)(32 * ((NSLOT + 31) / 32)) * (32 * ((NSLOT + 31) / 32)) * 4 : 0);
-    const size_t lds_c = ((size_t)fr.k * JC + fr_chunk_a_len(fr.kpad, fix)) * 8 + 72 * 4 + 8 * 64 * 8 + 64 * 8 + 64 * 4 + 16;
+    const bool fix = fr.wprev != nullptr;
+    const size_t dots_b = sizeof(T) == 4 ? (size_t)(32 * ((NSLOT + 31) / 32)) * (32 * ((NSLOT + 31) / 32)) * 4
+                                         : (size_t)(16 * ((NSLOT + 15) / 16)) * (16 * ((NSLOT + 15) / 16)) * 8;
+    const size_t lds_s = ((size_t)fr.k * JC + NSLOT * 16 + 32 + fr.kpad) * 8 + 16 + (fix ? dots_b : 0);
+    const size_t lds_c = ((size_t)fr.k * JC + fr_chunk_a_len(fr.kpad, fix, (int)sizeof(T))) * 8 + 72 * 4 + 8 * 64 * 8 + 64 * 8 + 64 * 4 + 16;
     const size_t lds_f = (size_t)sv_lds_doubles(NB) * 8;
     size_t lds = lds_s > lds_c ? lds_s : lds_c;
     if (lds_f > lds) lds = lds_f;

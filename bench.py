@@ -272,7 +272,7 @@ def main():
                                f"{args.cov_dtype} covariance, one independent sequence per GPU",
                    "sequences": world, "cov_kernel": args.cov_kernel,
                    "front": "stage kernels" if args.unfused else "fused front kernel",
-                   "sequence_mode": {"auto": "pipelined where it wins (f32 covariance, N >= 700 except N > 9000 with k > 96: "
+                   "sequence_mode": {"auto": "pipelined where it wins (N >= 700 except N > 9000 with k > 96: "
                                              "front kernel of frame t+1 beside the covariance update of frame t, "
                                              "covariance ping-pong between two buffers), else serial",
                                      "on": "pipelined", "off": "serial"}[args.lookahead]},
