@@ -143,6 +143,7 @@ struct ekf_filter {
     int last_m = 0;
     bool debug_w = false;
     bool debug_stamps = false;
+    bool debug_stamps_light = false;
     uint64_t fseq = 0;         // FUSED frames enqueued since reset: parity of the exchange buffer, frame tag
     uint64_t done_total = 0;   // column chunks of fused frames enqueued since reset
     uint64_t la_base = 0;      // frames that went through the pipelined sequence mode since reset (device counters)
@@ -218,6 +219,7 @@ EkfFrame make_frame(ekf_filter* f, const int32_t* idx_dev, const double* z_dev, 
     fr.traj_row = traj_row;
     fr.dxvec = f->at<double>(L.off_dx);
     fr.stamps = (f->debug_w || f->debug_stamps) ? f->at<long long>(L.off_stamps) : nullptr;
+    fr.stamps_heavy = f->debug_stamps_light ? 0 : 1;
     fr.nz = EkfNoise{f->cfg.q_cam, f->cfg.q_err, f->cfg.q_lm, f->cfg.r_uncertainty};
     fr.quat_mode = f->cfg.quat_mode;
     fr.n_lm = f->n_lm;
@@ -879,8 +881,9 @@ int ekf_debug_fetch(ekf_filter* f, int32_t what, double* out, size_t count) {
         f->debug_w = true;
         return EKF_OK;
     }
-    if (what == -2) {           // in-kernel time stamps only (no debug copies: the production code path)
+    if (what == -2 || what == -3) {   // in-kernel time stamps only (no debug copies: the production code path); -3: role level only
         f->debug_stamps = true;
+        f->debug_stamps_light = what == -3;
         return EKF_OK;
     }
     const Layout& L = f->lay;

@@ -131,31 +131,33 @@ __device__ __forceinline__ void fr_role_sblock(const EkfFrame& fr, int sb, int n
     // P round trips and the measurement model of the others; their operand loads do not depend on the indices.
     // (f64 covariance: the same with v_mfma_f64_16x16x4_f64 on 16 x 16 tiles, the f64 update's sequence.)
     const bool fix = fr.wsup_prev != nullptr;
-    constexpr int NT = (NSLOT + 31) / 32, DLD = 32 * NT, DR = NB < FR_DOT_RING ? NB : FR_DOT_RING;
-    constexpr int NT16 = (NSLOT + 15) / 16, DLD64 = 16 * NT16;
+    constexpr int NT16 = (NSLOT + 15) / 16, DLD16 = 16 * NT16, DLD64 = DLD16;
     double* dots64 = rsd + fr.kpad;                           // [16 NT16][16 NT16] (f64 covariance)
-    float* dots = reinterpret_cast<float*>(rsd + fr.kpad);    // [32 NT][32 NT]
-    const int dlane = tid & 63, dl31 = dlane & 31, dlhi = dlane >> 5, dtile = 7 - (tid >> 6);
-    const bool dotw = sizeof(T) == 4 && fix && dtile < NT * NT;
-    float ra[DR][8], rb[DR][8];
+    float* dots = reinterpret_cast<float*>(rsd + fr.kpad);    // [16 NT16][16 NT16] (f32 covariance)
+    const int dlane = tid & 63, dc = dlane & 15, dg = dlane >> 4, dtile = 7 - (tid >> 6);
+    // f32: 16 x 16 tiles of v_mfma_f32_16x16x4_f32 -- four fused multiply-adds per element and instruction over k
+    // ascending, the same chain as the covariance update's v_mfma_f32_32x32x2_f32 pairs (tools/probes/mfma_order_probe.hip:
+    // bit for bit on random data of mixed magnitudes) -- one tile per wave, the last waves first: a quarter of the
+    // matrix time of one 32 x 32 tile on one wave (48 x 64 cycles at k = 96, on the path of every S block).
+    // Operand A: lane (i = c, k = g) = -W_sup[4 s + g][row slot], B: lane (k = g, j = c); up to 24 k-steps in flight.
+    constexpr int KS4 = 4 * NB, KB = KS4 < 24 ? KS4 : 24;
+    const bool dotw = sizeof(T) == 4 && fix && dtile < NT16 * NT16;
     const float* __restrict__ wsd = static_cast<const float*>(fr.wsup_prev);
-    unsigned aoff = 0, boff = 0;
-    if (dotw) {
+    float oa[KB], ob[KB];
+    auto dot_operands = [&](int tile, int s0) {
         const int smax = fr.wsup_ld - 1;
-        const int rs = 32 * (dtile / NT) + dl31, cs = 32 * (dtile % NT) + dl31;
+        const int rs = 16 * (tile / NT16) + dc, cs = 16 * (tile % NT16) + dc;
         const int gr = (rs < EKF_CAM) ? rs : min(EKF_CAM + LMD * j0 + (rs - EKF_CAM), smax);
         const int gc = (cs < EKF_CAM) ? cs : min(EKF_CAM + LMD * jc0 + (cs - EKF_CAM), smax);
-        aoff = (unsigned)(dlhi * fr.wsup_ld + gr);      // A: lane (i = l31, k = lhi)
-        boff = (unsigned)(dlhi * fr.wsup_ld + gc);      // B: lane (k = lhi, j = l31)
 #pragma unroll
-        for (int c = 0; c < DR; ++c)
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const float* kb = wsd + (int64_t)(2 * (8 * c + u)) * fr.wsup_ld;      // (wave-uniform: scalar registers)
-                ra[c][u] = kb[aoff];
-                rb[c][u] = kb[boff];
+        for (int u = 0; u < KB; ++u)
+            if (s0 + u < KS4) {
+                const float* kb = wsd + (int64_t)(4 * (s0 + u) + dg) * fr.wsup_ld;
+                oa[u] = kb[gr];
+                ob[u] = kb[gc];
             }
-    }
+    };
+    if (dotw) dot_operands(dtile, 0);      // (they do not depend on the indices: in flight beside the index -> P round trips)
     if (tid < m) lmc[tid] = ekf_lm_column(fr, LMD, tid, false);
     __syncthreads();
     // this thread's entry of U (slot, c2): its P values are requested before the measurement model
@@ -184,33 +186,25 @@ __device__ __forceinline__ void fr_role_sblock(const EkfFrame& fr, int sb, int n
         }
     }
     if (dotw) {
-        fr_f32x16 dacc;
+        typedef float fr_f32x4 __attribute__((ext_vector_type(4)));
+        for (int tile = dtile; tile < NT16 * NT16; tile += 8) {
+            fr_f32x4 dacc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dacc[r] = 0.0f;
+            for (int s0 = 0; s0 < KS4; s0 += KB) {
+                if (tile != dtile || s0 != 0) dot_operands(tile, s0);
 #pragma unroll
-        for (int c = 0; c < NB; ++c) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) dacc = __builtin_amdgcn_mfma_f32_32x32x2f32(-ra[c % DR][u], rb[c % DR][u], dacc, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (c + DR < NB) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const float* kb = wsd + (int64_t)(2 * (8 * (c + DR) + u)) * fr.wsup_ld;
-                    ra[c % DR][u] = kb[aoff];
-                    rb[c % DR][u] = kb[boff];
-                }
+                for (int u = 0; u < KB; ++u)
+                    if (s0 + u < KS4) dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(-oa[u], ob[u], dacc, 0, 0, 0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // C / D layout: register reg <-> tile row (reg & 3) + 8 (reg >> 2) + 4 lhi, column l31
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg)
-            dots[(32 * (dtile / NT) + (reg & 3) + 8 * (reg >> 2) + 4 * dlhi) * DLD + 32 * (dtile % NT) + dl31] = dacc[reg];
+            for (int r = 0; r < 4; ++r)      // C / D layout: column c, row 4 g + r
+                dots[(16 * (tile / NT16) + 4 * dg + r) * DLD16 + 16 * (tile % NT16) + dc] = dacc[r];
+        }
     }
     if constexpr (sizeof(T) == 8) {
         if (fix) {      // f64: 16 x 16 tiles, the last waves first; A[i = c][k = g] = -W_sup[4 s + g][row slot], B[k = g][j = c]
             const double* __restrict__ w64 = static_cast<const double*>(fr.wsup_prev);
-            const int dc = dlane & 15, dg = dlane >> 4, smax = fr.wsup_ld - 1;
+            const int smax = fr.wsup_ld - 1;
             for (int tile = dtile; tile < NT16 * NT16; tile += 8) {
                 const int rs = 16 * (tile / NT16) + dc, cs = 16 * (tile % NT16) + dc;
                 const int gr = (rs < EKF_CAM) ? rs : min(EKF_CAM + LMD * j0 + (rs - EKF_CAM), smax);
@@ -248,7 +242,7 @@ __device__ __forceinline__ void fr_role_sblock(const EkfFrame& fr, int sb, int n
                     const int cs = (b < EKF_CAM) ? b : cdet + (b - EKF_CAM);
                     if constexpr (sizeof(T) == 4) {
                         const float q = (col == urho[n]) ? (float)ekf_qdiag(urho[n], fr.dims, fr.nz) : 0.0f;
-                        pv[n][b] = (T)(((float)pv[n][b] + q) + dots[uslot * DLD + cs]);
+                        pv[n][b] = (T)(((float)pv[n][b] + q) + dots[uslot * DLD16 + cs]);
                     } else {      // (the f64 update: v = P; if (diagonal) v += Q; v += acc)
                         double v = (double)pv[n][b];
                         if (col == urho[n]) v += ekf_qdiag(urho[n], fr.dims, fr.nz);
@@ -440,18 +434,19 @@ struct SvIoFused {
             const double* p0 = fr.xs + sv_blk_index(r1, min(tc, r1)) + 2 * lane;
             if (!(has1 && i1 == NB)) z1[tc] = sf64x4{ekf_ldc(p0), ekf_ldc(p0 + 1), ekf_ldc(p0 + 128), ekf_ldc(p0 + 129)};
         }
+        // (every tag is consumed here, also those of the clamped duplicates -- they are tags of real blocks of this
+        // frame: a load whose result is never used stays "pending" for the compiler, which then waits for it, and for
+        // every younger store, wherever the register is reused)
 #pragma unroll
-        for (int tc = C0; tc < N0 && tc < C1; ++tc)
-            if (blk0 && tc <= i0) {
-                settle_block(z0[tc], i0, tc, lane);
-                stale |= fr_tag_stale(t0[tc], fr.seqno);
-            }
+        for (int tc = C0; tc < N0 && tc < C1; ++tc) {
+            stale |= fr_tag_stale(t0[tc], fr.seqno);
+            if (blk0 && tc <= i0) settle_block(z0[tc], i0, tc, lane);
+        }
 #pragma unroll
-        for (int tc = C0; tc < N1 && tc < C1; ++tc)
-            if (blk1 && tc <= i1) {
-                settle_block(z1[tc], i1, tc, lane);
-                stale |= fr_tag_stale(t1[tc], fr.seqno);
-            }
+        for (int tc = C0; tc < N1 && tc < C1; ++tc) {
+            stale |= fr_tag_stale(t1[tc], fr.seqno);
+            if (blk1 && tc <= i1) settle_block(z1[tc], i1, tc, lane);
+        }
         // the residual row (one wave): z - h, replicated in all 16 rows of its "block".  All loads first, THEN the
         // sentinel checks (one round trip)
         if (res0) {
@@ -550,7 +545,7 @@ __device__ __forceinline__ void fr_panel_pre(const EkfFrame& fr, FrPre<NB>& pre,
 }
 
 template <typename T, int NB, int MODEL>
-__device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds, volatile int* sync, double* pshare,
+__device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds, volatile ekf_lds_int* sync, double* pshare,
                                          int wv, int col0, int lane, int& spin_fail, FrPre<NB>& pre) {
     const int j = lane & 15, g = lane >> 4;
     const double* __restrict__ xlop = fr.xl;
@@ -670,7 +665,7 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
                 yq[r] = pshare[(4 + r) * 64 + lane];
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the reads before the acknowledgement
-            if (lane == 0) atomicAdd(const_cast<int*>(sync) + 1, 1);
+            if (lane == 0) __hip_atomic_fetch_add(const_cast<ekf_lds_int*>(sync) + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         if (AHEAD && q + 1 < NB) {                   // (before this step's W stores: a wait for a load also waits for every older store)
             if ((q & 1) == 0) issue_l(lqb, q + 1);
@@ -803,7 +798,7 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
             hs[e] = v;
         }
         if (spin) atomicOr(fr.status, EKF_ST_TIMEOUT);
-        if (fr.stamps && chunk == 0 && tid == 0 && NB <= 6) fr.stamps[44] = wall_clock64();
+        if (fr.stamps && fr.stamps_heavy && chunk == 0 && tid == 0 && NB <= 6) fr.stamps[44] = wall_clock64();
         if (tid == 0) {
             const double tag = ekf_ldc(fr.xl + fr.xl_tag);
             if (fr_tag_stale(tag, fr.seqno)) atomicOr(fr.status, EKF_ST_STALE_JAC);
@@ -858,7 +853,7 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
         const float* __restrict__ Pf = static_cast<const float*>(fr.cov);
         const int nslots = EKF_CAM + LMD * m;
         const int lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
-        const bool stp_c = fr.stamps && chunk == 0 && tid == 0 && NB <= 6;
+        const bool stp_c = fr.stamps && fr.stamps_heavy && chunk == 0 && tid == 0 && NB <= 6;
         if (stp_c) fr.stamps[41] = wall_clock64();
         for (int round = 0; 128 * round < nslots; ++round) {
             const int tile_l = g >> 1, tile_i = 4 * round + tile_l, jl = 32 * (g & 1);
@@ -1033,7 +1028,7 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
     if (!fix) fetch_jacobian();
     __syncthreads();
     FrPre<NB> pre;
-    if (fr.stamps && chunk == 0 && tid == 0 && NB <= 6) fr.stamps[14] = wall_clock64();
+    if (fr.stamps && fr.stamps_heavy && chunk == 0 && tid == 0 && NB <= 6) fr.stamps[14] = wall_clock64();
     // (the support rows become doubles BEFORE the substitution's first requests go out: they may come straight from
     // memory, and a wait for them placed after those requests would wait for the requests too)
     double pc[EKF_CAM], pld[NU][LMD];
@@ -1047,7 +1042,7 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
     }
     asm volatile("" ::: "memory");
     if (g < 4) fr_panel_pre<NB, MODEL>(fr, pre, smask_l, g, chunk0 + 16 * g, tid & 63);
-    if (fr.stamps && chunk == 0 && tid == 0 && NB <= 6) fr.stamps[15] = wall_clock64();
+    if (fr.stamps && fr.stamps_heavy && chunk == 0 && tid == 0 && NB <= 6) fr.stamps[15] = wall_clock64();
     // (hs is only read and the A chunk only written here: without `restrict` every row's Jacobian reads waited for the
     // previous row's store)
     const double* __restrict__ hsr = hs;
@@ -1077,7 +1072,7 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
     int spin_fail = 0;
     if (g < 4) {
         const int lane = tid & 63, col0 = chunk0 + 16 * g;
-        fr_panel<T, NB, MODEL>(fr, a_lds, flag + 1, pshare, g, col0, lane, spin_fail, pre);
+        fr_panel<T, NB, MODEL>(fr, a_lds, ekf_lds_flags(flag + 1), pshare, g, col0, lane, spin_fail, pre);
         if (spin_fail && (tid & 63) == 0) atomicOr(fr.status, EKF_ST_TIMEOUT);
     }
     if (MODEL == 0) return;

@@ -51,6 +51,8 @@ struct EkfFrame {
     double* traj_row;      // optional: state[0:7] after the update
     double* dxvec;         // model 1: dx = W^T y for every state dimension (input of the injection kernel)
     long long* stamps;     // optional: s_memtime stamps of the solve kernel's phases (diagnostics)
+    int32_t stamps_heavy;  // 0: only the stamps at the start / end of the roles (a stamp is a global store: the wave that takes it
+                           // later waits for its acknowledgement), 1: also inside the factorisation and the chunk prologue
     // Pipelined sequence mode (ekf_api.hip: ekf_observe_sequence_device).  The covariance lives in TWO buffers: the
     // update of frame t reads `cov` (P_t) and writes `cov_out` (P_{t+1}); the front kernel of frame t+1 runs beside it
     // and takes the entries of P_{t+1} it needs -- support rows only -- from P_t and W_t on the fly:

@@ -22,6 +22,14 @@ template <bool COH> __device__ __forceinline__ double ekf_ldx(const double* p) {
 
 typedef double sf64x4 __attribute__((ext_vector_type(4)));
 
+// Flag words in LDS that waves poll.  The accesses have to be volatile -- and a volatile access through a GENERIC
+// pointer stays a flat access (the address-space inference leaves volatile accesses alone): `flat_load_dword ... sc0
+// sc1` + `s_waitcnt vmcnt(0)`, so every poll also waited for every global store the wave had in flight (the
+// write-through publication stores of the factorisation, the W rows of the substitution: 0.5 - 1 us per poll).
+// Through an LDS-qualified pointer the same access is a ds_read_b32 that only counts in lgkmcnt.
+typedef __attribute__((address_space(3))) int ekf_lds_int;
+__device__ __forceinline__ volatile ekf_lds_int* ekf_lds_flags(void* p) { return (volatile ekf_lds_int*)p; }
+
 __device__ __forceinline__ double ekf_readlane_f64(double v, int src) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
@@ -144,7 +152,7 @@ struct SvChain {
     sf64x4 m;        // the block (C layout) on entry; destroyed
     sf64x4 lp;       // debug: OP layout of L' (unit lower)
     sf64x4 dr;       // debug: pivots by g + 4 rr
-    double dcol;     // pivot d_c in every lane with lane & 15 == c
+    int dlo, dhi;    // pivot d_J in lane J (the 16 lanes of row group 0), as two dwords (v_writelane)
     int bad;
 };
 template <int J, bool DBG>
@@ -157,11 +165,13 @@ __device__ __forceinline__ void sv_pivot(SvChain& s, sf64x4& u, double& rowv, in
         a1 = ekf_readlane_f64(s.m[R1], 16 * G1 + J);                 // M[J + 1][J]
     }
     const double d = ekf_readlane_f64(rowv, J);                      // M[J][J]
-    s.bad |= !(d > 0.0);
     const double r = sv_rcp(d);
-    s.dcol = (c == J) ? d : s.dcol;
+    // (the chain is bound by its instruction count: the pivot goes into lane J with two v_writelane instead of a
+    // compare and four moves / selects, and its sign is checked once at the end, for all 16 at a time)
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(s.dlo) : "s"(__double2loint(d)), "n"(J));
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(s.dhi) : "s"(__double2hiint(d)), "n"(J));
     const double lc = rowv * r;                                      // L'[c][J] (c >= J; 1 on the diagonal)
-    const double nl = (c > J) ? -lc : 0.0;                           // strictly below the pivot: row / column J themselves stay
+    double nl = (c > J) ? -lc : 0.0;                                 // strictly below the pivot: row / column J themselves stay
     if (DBG) {
         s.lp[R] = (g == G0) ? lc : s.lp[R];
         s.dr[R] = (g == G0) ? d : s.dr[R];
@@ -180,8 +190,11 @@ __device__ __forceinline__ void sv_pivot(SvChain& s, sf64x4& u, double& rowv, in
                  "v_fmac_f64_dpp %6, %6, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
                  "v_fmac_f64_dpp %7, %7, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
                  "s_nop 1"
-                 : "+v"(s.m[0]), "+v"(s.m[1]), "+v"(s.m[2]), "+v"(s.m[3]), "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3])
-                 : "v"(nl), "n"(J));
+                 : "+v"(s.m[0]), "+v"(s.m[1]), "+v"(s.m[2]), "+v"(s.m[3]), "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]),
+                   "+v"(nl)       // (formally an output too: the row update below -- the first use of the broadcast that was
+                                  // requested above -- must stay BEHIND the eight FMAs, or hipcc hoists it, and the wait for
+                                  // the LDS crossbar with it, in front of them: then only the reciprocal overlaps that latency)
+                 : "n"(J));
     rowv = __builtin_fma(a1, nl, nxt);                               // M[J + 1][c] after update J (c > J)
 }
 // In: s.m.  Out: xop = OP layout of X = L^-1 (`dop` order), s.dcol (and s.lp, s.dr with DBG); returns != 0
@@ -189,7 +202,8 @@ __device__ __forceinline__ void sv_pivot(SvChain& s, sf64x4& u, double& rowv, in
 template <bool DBG>
 __device__ __forceinline__ int sv_chain_t(SvChain& s, sf64x4& xop, int c, int g) {
     s.bad = 0;
-    s.dcol = 1.0;
+    s.dlo = 0;
+    s.dhi = 0x3ff00000;
     sf64x4 u;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -205,13 +219,29 @@ __device__ __forceinline__ int sv_chain_t(SvChain& s, sf64x4& xop, int c, int g)
     sv_pivot<12, DBG>(s, u, rowv, c, g);  sv_pivot<13, DBG>(s, u, rowv, c, g);  sv_pivot<14, DBG>(s, u, rowv, c, g);
     sv_pivot<15, DBG>(s, u, rowv, c, g);
     // X = D^-1/2 L'^-1: row c of the OP layout is scaled by 1 / sqrt(d_c)
-    const double rs = ekf_rsqrt_f64(s.dcol);
+    const double dcol = sv_group_bcast<0>(__hiloint2double(s.dhi, s.dlo));      // d_c in every lane with lane & 15 == c
+    s.bad = !(dcol > 0.0);
+    const double rs = ekf_rsqrt_f64(dcol);
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) xop[rr] = u[rr] * rs;
     return __any(s.bad);
 }
-__device__ __forceinline__ int sv_chain(SvChain& s, sf64x4& xop, int c, int g, bool dbg) {
-    return dbg ? sv_chain_t<true>(s, xop, c, g) : sv_chain_t<false>(s, xop, c, g);
+// ONE copy of the chain's code per kernel (a real call, arguments and results in registers): the front kernel runs
+// every piece of its straight-line code once per launch, i.e. from a cold instruction cache (120 - 150 KB of code at
+// k = 96, a 64 KB cache shared by two CUs), and the chain is the serial part everything else waits for.  Inlined, each
+// of the NB chains was a fresh 4.4 KB of code.  As a function the first call warms the cache for the others -- and
+// sv_factor makes that first call on an idle wave while the S blocks are still on their way.  (The callee starts with
+// `s_waitcnt vmcnt(0)`, as every function does: free, as long as the calling wave has no store in flight -- see PUB.)
+struct SvChainRes {
+    sf64x4 xop;
+    int bad;
+};
+__device__ inline __attribute__((noinline)) SvChainRes sv_chain_shared(sf64x4 m, int lane) {
+    SvChain s;
+    s.m = m;
+    SvChainRes res;
+    res.bad = sv_chain_t<false>(s, res.xop, lane & 15, lane >> 4);
+    return res;
 }
 
 // One S block from its LDS tile (row-major [16][17]; on a diagonal block the lower triangle is
@@ -323,7 +353,7 @@ __device__ __forceinline__ void sv_factor(const EkfFrame& fr, IO& io, double* ld
     double* ybuf = lds + 512;                       // [NB + 1][256]  OP(L_ib) of the current block column
     // yflag[i] = b + 1 once row i's L_ib of block column b is in ybuf (the rows publish at slightly different
     // times; a hardware barrier there would make the next chain wait for the slowest panel)
-    volatile int* yflag = reinterpret_cast<volatile int*>(lds + 512 + (NB + 1) * 256);
+    volatile ekf_lds_int* yflag = ekf_lds_flags(lds + 512 + (NB + 1) * 256);
     if (tid <= NB) yflag[tid] = 0;
     __syncthreads();
     auto wait_row = [&](int row, int b) {           // row's block of column b is in ybuf
@@ -345,11 +375,35 @@ __device__ __forceinline__ void sv_factor(const EkfFrame& fr, IO& io, double* ld
     // do (b even: row b + 1, whose blocks are all covered by the urgent updates below).
     const int i0 = 2 * (wave & 3) + (wave >> 2), i1 = i0 + 8;
     const bool has0 = i0 <= NB, has1 = TWO && i1 <= NB;
+    // Up to NB = 6 the last wave owns no row: it does ALL the publishing (Dinv, -L, y: from the LDS copies the other
+    // waves leave anyway), so that no wave that computes ever has a global store in flight.  A wait for ANYTHING that
+    // counts in vmcnt -- and hipcc places conservative `s_waitcnt vmcnt(0)` wherever a register with a formally
+    // pending load is reused, e.g. at the top of the next chain -- also waits for every older store of the wave, and
+    // the acknowledgement of a write-through store takes 1 - 2k cycles beside the covariance update's traffic: with
+    // every row publishing its own block, that was the larger part of the hand-over between two chains.
+    constexpr bool PUB = NB <= 6;
+    const bool is_pub = PUB && wave == SV_NW - 1;
     sf64x4 z0[N0], z1[N1];
     // optional time stamps (debug): [0] start, [1] blocks in registers, [2 + 2 b] chain phase of block column b
     // over (barrier), [3 + 2 b] panel + urgent update over; [47 + 2 b], [48 + 2 b] the chain alone (b < 4)
-    long long* stp = (fr.stamps && lane == 0) ? fr.stamps : nullptr;
+    long long* stp = (fr.stamps && fr.stamps_heavy && lane == 0) ? fr.stamps : nullptr;
+    // Inside the loop the stamps stay in registers and are stored at the very end: a stamp that is stored at once is a
+    // global store, and the wave that took it later waits for its acknowledgement -- it perturbs what it measures.
+    constexpr int NTS = NB <= 6 ? NB : 1;
+    long long ts_cs[NTS], ts_ce[NTS], ts_bar[NTS], ts_pan[NTS], ts_ph3[NTS];
+#pragma unroll
+    for (int q = 0; q < NTS; ++q) ts_cs[q] = ts_ce[q] = ts_bar[q] = ts_pan[q] = ts_ph3[q] = 0;
     if (stp && wave == 0) stp[0] = clock64();
+    // (light stamps: taken by the publishing wave, whose stores delay nobody)
+    long long* stl = (fr.stamps && !fr.stamps_heavy && is_pub && lane == 0) ? fr.stamps : nullptr;
+    if (stl) stl[0] = clock64();
+    if (wave == SV_NW - 1) {      // warm the instruction cache (per CU) with the chain's code: identity block, result unused
+        sf64x4 idm;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) idm[r] = (g + 4 * r == c) ? 1.0 : 0.0;
+        const SvChainRes warm = sv_chain_shared(idm, lane);
+        asm volatile("" ::"v"(warm.xop[0]), "v"(warm.bad));
+    }
     // block column 0 first (all the first chain and the first panel need); the other block columns come in
     // beside the first chain
     io.template load_cols<NB, N0, N1, 0, 1>(z0, z1, i0, i1, has0, has1, lane, g);
@@ -364,13 +418,19 @@ __device__ __forceinline__ void sv_factor(const EkfFrame& fr, IO& io, double* ld
             SvChain s;
             s.m = (b < 8) ? z0[b < N0 ? b : 0] : z1[b < N1 ? b : 0];
             sf64x4 xop;
-            if (stp && b < 4) stp[47 + 2 * b] = clock64();
-            const int badnow = sv_chain(s, xop, c, g, fr.wdbg != nullptr);
-            if (stp && b < 4) stp[48 + 2 * b] = clock64();
+            if (stp && b < NTS) ts_cs[b < NTS ? b : 0] = clock64();
+            int badnow;
+            if (fr.wdbg) badnow = sv_chain_t<true>(s, xop, c, g);      // (tests: also L' and the pivots)
+            else {
+                const SvChainRes res = sv_chain_shared(s.m, lane);
+                xop = res.xop;
+                badnow = res.bad;
+            }
+            if (stp && b < NTS) ts_ce[b < NTS ? b : 0] = clock64();
             if (badnow && !bad) badcol = 100 + b;
             bad |= badnow;
             sv_lds_put(xbuf0 + (b & 1) * 256, xop, lane);
-            io.put_dinv(b, xop, lane);
+            if (!PUB) io.put_dinv(b, xop, lane);
             if (fr.wdbg) {                            // dense L for tests only: L_bb = L' D^1/2
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -397,7 +457,8 @@ __device__ __forceinline__ void sv_factor(const EkfFrame& fr, IO& io, double* ld
                 }
         }
         __syncthreads();
-        if (stp && wave == 0) stp[2 + 2 * b] = clock64();
+        if (stp && b < NTS) ts_bar[b < NTS ? b : 0] = clock64();
+        if (stl) stl[2 + 2 * b] = clock64();
         // ---- phase 2: panel
         {
             const sf64x4 xop = sv_lds_get(xbuf0 + (b & 1) * 256, lane);
@@ -412,14 +473,28 @@ __device__ __forceinline__ void sv_factor(const EkfFrame& fr, IO& io, double* ld
                 post_row(i1, b);
             }
         }
+        if (stp && b < NTS) ts_pan[b < NTS ? b : 0] = clock64();
         // publication / emission: -L blocks in `lop` order (the registers as they are), y of the residual row
-        if (has0 && i0 > b) {
-            if (i0 < NB) io.put_l(i0, b, y0, lane);
-            else io.put_y(b, (c >> 2) == 0 ? y0[0] : (c >> 2) == 1 ? y0[1] : (c >> 2) == 2 ? y0[2] : y0[3], c, g == (c & 3));
-        }
-        if (has1 && i1 > b) {
-            if (i1 < NB) io.put_l(i1, b, y1, lane);
-            else io.put_y(b, (c >> 2) == 0 ? y1[0] : (c >> 2) == 1 ? y1[1] : (c >> 2) == 2 ? y1[2] : y1[3], c, g == (c & 3));
+        if (!PUB) {
+            if (has0 && i0 > b) {
+                if (i0 < NB) io.put_l(i0, b, y0, lane);
+                else io.put_y(b, (c >> 2) == 0 ? y0[0] : (c >> 2) == 1 ? y0[1] : (c >> 2) == 2 ? y0[2] : y0[3], c, g == (c & 3));
+            }
+            if (has1 && i1 > b) {
+                if (i1 < NB) io.put_l(i1, b, y1, lane);
+                else io.put_y(b, (c >> 2) == 0 ? y1[0] : (c >> 2) == 1 ? y1[1] : (c >> 2) == 2 ? y1[2] : y1[3], c, g == (c & 3));
+            }
+        } else if (is_pub) {
+            // (X_b stays in its slot until chain b + 2 is over and L_ib in its slot until the panel of step b + 1: both
+            // come after the next barrier, which this wave only reaches when it has read them)
+            io.put_dinv(b, sv_lds_get(xbuf0 + (b & 1) * 256, lane), lane);
+#pragma unroll
+            for (int i = b + 1; i <= NB; ++i) {
+                wait_row(i, b);
+                const sf64x4 yi = sv_lds_get(ybuf + i * 256, lane);
+                if (i < NB) io.put_l(i, b, yi, lane);
+                else io.put_y(b, (c >> 2) == 0 ? yi[0] : (c >> 2) == 1 ? yi[1] : (c >> 2) == 2 ? yi[2] : yi[3], c, g == (c & 3));
+            }
         }
         if (fr.wdbg) {
 #pragma unroll
@@ -451,6 +526,20 @@ __device__ __forceinline__ void sv_factor(const EkfFrame& fr, IO& io, double* ld
                 }
             }
         }
-        if (stp && wave == 0) stp[3 + 2 * b] = clock64();
+        if (stp && b < NTS) ts_ph3[b < NTS ? b : 0] = clock64();
+    }
+    if (stp) {      // [2 + 2 b] barrier, [3 + 2 b] end of step (wave 0); chain start / end (its owner); [16 + b] panel posted (row b + 1)
+#pragma unroll
+        for (int b = 0; b < NTS; ++b) {
+            if (wave == 0) {
+                stp[2 + 2 * b] = ts_bar[b];
+                stp[3 + 2 * b] = ts_ph3[b];
+            }
+            if (wave == ((b & 7) >> 1) + 4 * (b & 1)) {
+                stp[(b < 4 ? 47 : 48) + 2 * b] = ts_cs[b];
+                stp[(b < 4 ? 48 : 49) + 2 * b] = ts_ce[b];
+            }
+            if (has0 && i0 == b + 1) stp[16 + b] = ts_pan[b];
+        }
     }
 }

@@ -291,10 +291,11 @@ class HipEkf:
         dummy = np.zeros(1)
         self._check(self.lib.ekf_debug_fetch(self.h, -1, _dptr(dummy), 1))
 
-    def debug_enable_stamps(self):
-        """In-kernel time stamps of the front kernel without the debug copies of W / L (production code path)."""
+    def debug_enable_stamps(self, light: bool = False):
+        """In-kernel time stamps of the front kernel without the debug copies of W / L (production code path).
+        `light`: only the stamps at the start / end of the roles (the others perturb what they measure)."""
         dummy = np.zeros(1)
-        self._check(self.lib.ekf_debug_fetch(self.h, -2, _dptr(dummy), 1))
+        self._check(self.lib.ekf_debug_fetch(self.h, -3 if light else -2, _dptr(dummy), 1))
 
     def debug_fetch(self, what: str, m: int):
         rd = self.rows_per_detection
