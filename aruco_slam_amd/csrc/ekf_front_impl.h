@@ -392,8 +392,8 @@ struct SvIoFused {
         return v;
     }
     // Block columns [C0, C1) of the wave's rows into registers (and, with C0 == 0, the whole residual row if the
-    // wave owns it).  One polled word per block (its last), all polls of a round in flight together; then tags and
-    // bulk, all in flight together; then the per-word sentinel check.  Branch-free issue: block indices are clamped
+    // wave owns it).  Tags and bulk, all in flight together; then the per-word sentinel check, block by block, fetching
+    // a block again until every word of it has landed.  Branch-free issue: block indices are clamped
     // instead of guarded, so that the loads of a round sit in one basic block and all go out before the first
     // result is needed (guarded loads were waited for one by one: ~1.2 us per block).
     template <int NB, int N0, int N1, int C0, int C1>
@@ -402,21 +402,9 @@ struct SvIoFused {
         const bool blk0 = has0 && i0 < NB, blk1 = has1 && i1 < NB;       // S-block rows (not the residual)
         const bool res0 = C0 == 0 && has0 && i0 == NB, res1 = C0 == 0 && has1 && i1 == NB;
         const int r0 = blk0 ? i0 : 0, r1 = blk1 ? i1 : r0;
-        if (C0 == 0) {      // (the later block columns are fetched beside the first chain, ~1.5 us after these have been seen:
-                            // no polling round for them, a straggler goes down the settle path)
-            const double* wr = (res0 || res1) ? fr.xr + 15 : fr.xs + sv_blk_index(r0, min(C0, r0)) + 255;
-            int it = 0;
-            for (;;) {
-                int pend = (int)ekf_is_sent(ekf_ldc(wr));
-#pragma unroll
-                for (int tc = C0; tc < N0 && tc < C1; ++tc) pend |= (int)ekf_is_sent(ekf_ldc(fr.xs + sv_blk_index(r0, min(tc, r0)) + 255));
-#pragma unroll
-                for (int tc = C0; tc < N1 && tc < C1; ++tc) pend |= (int)ekf_is_sent(ekf_ldc(fr.xs + sv_blk_index(r1, min(tc, r1)) + 255));
-                if (!pend) break;
-                if (++it > EKF_SPIN_MAX) { spin_fail = 1; break; }
-                ekf_poll_sleep();
-            }
-        }
+        // No separate polling round: tags and bulk go out at once and every block is fetched again until all its
+        // words have landed (settle_block).  Polling one word per block first cost a memory round trip between "the
+        // block is there" and "the block is in registers", on the path to the first chain.
         double t0[N0], t1[N1];
 #pragma unroll
         for (int tc = C0; tc < N0 && tc < C1; ++tc) t0[tc] = ekf_ldc(fr.xs_tag + 16 * min(tc, r0) + r0);
@@ -504,6 +492,12 @@ __device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, double* v_sm)
         }
     }
     if (fr.stamps && tid == 0) fr.stamps[63] = wall_clock64();
+    // the S-block tags once more, now that every one of them has landed (the copy that travelled with the bulk may have
+    // been read before its producer had written it: it then counted as "no objection")
+    if (tid < 256) {
+        const int tc = tid >> 4, i = tid & 15;
+        if (tc <= i && i < NB && fr_tag_stale(ekf_ldc(fr.xs_tag + 16 * tc + i), fr.seqno)) atomicOr(fr.status, EKF_ST_STALE_S);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -521,7 +515,7 @@ __device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, double* v_sm)
 template <int NB>
 struct FrPre {
     static constexpr int LG = (NB >= 11) ? 4 : 6;
-    double lqa[LG][4], dqn[4], yqn[4], tagn;
+    double lqa[LG][4], dqn[4], yqn[4];
     unsigned long long smask;       // next-frame detections whose landmark owns this lane's column (duplicates possible)
     int sdim;
 };
@@ -538,7 +532,6 @@ __device__ __forceinline__ void fr_panel_pre(const EkfFrame& fr, FrPre<NB>& pre,
         pre.dqn[r] = (wv == 0) ? ekf_ldc(fr.xl + fr.xl_dop + (size_t)r * 64 + lane) : 0.0;
         pre.yqn[r] = (wv == 0) ? ekf_ldc(fr.xl + fr.xl_y + g + 4 * r) : 0.0;
     }
-    pre.tagn = (wv == 0) ? ekf_ldc(fr.xl + fr.xl_tag + 1) : 0.0;
     const int mycol = col0 + j;
     pre.smask = fr.wsup ? smask_l[16 * wv + j] : 0ull;
     pre.sdim = (mycol >= EKF_CAM) ? (mycol - EKF_CAM) % EkfModel<MODEL>::LMD : 0;
@@ -599,8 +592,6 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
             dqn[r] = ekf_ldc(xdop + (size_t)(q * 4 + r) * 64 + lane);
             yqn[r] = ekf_ldc(xy + 16 * q + g + 4 * r);
         }
-        pre.tagn = ekf_ldc(fr.xl + fr.xl_tag + 1 + q);      // (checked when the column is used: a load that is used at once
-                                                             // would make the wave wait for everything it has just requested)
     };
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
@@ -609,7 +600,6 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
         if (wv == 0) {
             // sync[0] = block columns shared so far, sync[1] = reads of the shared slot acknowledged
             bool pend = false;
-            double tag = pre.tagn;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 dq[r] = dqn[r];
@@ -617,13 +607,10 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
                 pend = pend || ekf_is_sent(dq[r]) || ekf_is_sent(yq[r]);
             }
             if (__any(pend)) {
-                int it = 0;
-                if (q < NB - 1)      // (the last block column is polled on the data itself: one round trip less)
-                    while (ekf_is_sent(ekf_ldc(xdop + (size_t)(q * 4 + 3) * 64 + 63))) {      // the word written last
-                        if (++it > EKF_SPIN_MAX) { spin_fail = 1; break; }
-                        ekf_poll_sleep();
-                    }
-                for (it = 0;; ++it) {
+                // (polled on the data itself: a poll of one word first, then the bulk, then the tag were three dependent
+                // memory round trips between "published" and "used" whenever the chunk waits for the factorisation --
+                // the last block columns, i.e. the tail of the launch)
+                for (int it = 0;; ++it) {
                     pend = false;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -635,9 +622,7 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
                     if (it > EKF_SPIN_MAX) { spin_fail = 1; break; }
                     ekf_poll_sleep();
                 }
-                tag = ekf_ldc(fr.xl + fr.xl_tag + 1 + q);
             }
-            if (lane == 0 && fr_tag_stale(tag, fr.seqno)) atomicOr(fr.status, EKF_ST_STALE_COL);
             int it = 0;
             while (sync[1] < 3 * q) {                  // the slot's previous content has been read
                 if (++it > 64 * EKF_SPIN_MAX) { spin_fail = 1; break; }
@@ -753,6 +738,10 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
         }
     }
     if (stp) stp[NB] = wall_clock64();
+    // the frame tags of the factor's block columns, all at once and after everything that depended on them has been
+    // issued (a status bit is all they can raise; checked inside the steps they were a round trip per block column)
+    if (wv == 0 && lane < NB && fr_tag_stale(ekf_ldc(fr.xl + fr.xl_tag + 1 + lane), fr.seqno)) atomicOr(fr.status, EKF_ST_STALE_COL);
+    if (wv == 0 && lane == NB && fr_tag_stale(ekf_ldc(fr.xl + fr.xl_tag), fr.seqno)) atomicOr(fr.status, EKF_ST_STALE_JAC);
 }
 
 template <typename T, int NU, int MODEL, int NB>
@@ -775,34 +764,38 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
     if (fr.stamps && chunk == 0 && tid == 0) fr.stamps[32] = wall_clock64();
     // Jacobian rows: published by the measurement workgroup (this role never reads the state, so the
     // injection at the end of the launch cannot race with a chunk that starts late)
-    auto fetch_jacobian = [&]() {
-        const double* __restrict__ xj = fr.xl + fr.xl_jac;
-        const int nel = fr.k * JC;
+    // Two halves: the requests go out early (pipelined mode: before the matrix phase of the support rows, which does not
+    // need them) and the values are taken, checked against the sentinel (fetched again until they have landed) and put
+    // into LDS when the A chunk is about to be built.  Polled on the data itself, tag with the bulk (checked once more at
+    // the end of the role: fr_panel).
+    constexpr int NJ = (16 * NB * JC + FR_T - 1) / FR_T;
+    double jv[NJ], jtag = 0.0;
+    const double* __restrict__ xj = fr.xl + fr.xl_jac;
+    const int nel = fr.k * JC;
+    auto jac_issue = [&]() {
+#pragma unroll
+        for (int n = 0; n < NJ; ++n) jv[n] = ekf_ldc(xj + min(tid + FR_T * n, nel - 1));
+        if (tid == 0) jtag = ekf_ldc(fr.xl + fr.xl_tag);
+    };
+    auto jac_finish = [&]() {
         int spin = 0;
-        if (tid < 64) {        // one wave polls one word (the last one written)
-            int it = 0;
-            while (ekf_is_sent(ekf_ldc(xj + nel - 1))) {
-                if (++it > EKF_SPIN_MAX) { spin = 1; break; }
-                ekf_poll_sleep();
+#pragma unroll
+        for (int n = 0; n < NJ; ++n) {
+            const int e = tid + FR_T * n;
+            if (e < nel) {
+                double v = jv[n];
+                int it = 0;
+                while (ekf_is_sent(v)) {
+                    if (++it > EKF_SPIN_MAX) { spin = 1; break; }
+                    ekf_poll_sleep();
+                    v = ekf_ldc(xj + e);
+                }
+                hs[e] = v;
             }
-        }
-        __syncthreads();
-        for (int e = tid; e < nel; e += FR_T) {
-            double v = ekf_ldt(xj + e, false);
-            int it = 0;
-            while (ekf_is_sent(v)) {
-                if (++it > EKF_SPIN_MAX) { spin = 1; break; }
-                ekf_poll_sleep();
-                v = ekf_ldc(xj + e);
-            }
-            hs[e] = v;
         }
         if (spin) atomicOr(fr.status, EKF_ST_TIMEOUT);
         if (fr.stamps && fr.stamps_heavy && chunk == 0 && tid == 0 && NB <= 6) fr.stamps[44] = wall_clock64();
-        if (tid == 0) {
-            const double tag = ekf_ldc(fr.xl + fr.xl_tag);
-            if (fr_tag_stale(tag, fr.seqno)) atomicOr(fr.status, EKF_ST_STALE_JAC);
-        }
+        if (tid == 0 && fr_tag_stale(jtag, fr.seqno)) atomicOr(fr.status, EKF_ST_STALE_JAC);
     };
     T pcr[EKF_CAM];
     T plr[NU][LMD];
@@ -862,6 +855,7 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
             float pt[16];
+            unsigned dmask = 0;
 #pragma unroll
             for (int kb = 0; kb < NB; kb += FR_KS / 16) {
                 constexpr int NA = FR_KS * 32 / FR_T, NBL = FR_KS * 16 / FR_T;      // 16-byte loads per thread
@@ -886,16 +880,16 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
                         const int sj = min(max((slot - EKF_CAM) / LMD, 0), m - 1);
                         const int prw = (slot < EKF_CAM) ? slot : (slot < nslots ? lmc[sj] + (slot - EKF_CAM) % LMD : 0);
                         pt[reg] = Pf[(int64_t)prw * ld + chunk0 + jl + l31];
+                        dmask |= (unsigned)(prw == chunk0 + jl + l31) << reg;      // (diagonal entries: they get Q)
                     }
                 }
-                // the Jacobian rows arrive while the stage is in flight (hs is a region of its own)
-                if (kb == 0 && round == 0) fetch_jacobian();
                 if (kb > 0) __syncthreads();                   // the previous stage has been consumed
 #pragma unroll
                 for (int n = 0; n < NA; ++n) *reinterpret_cast<fr_f4*>(sA + 4 * (tid + FR_T * n)) = va[n];
 #pragma unroll
                 for (int n = 0; n < NBL; ++n) *reinterpret_cast<fr_f4*>(sB + 4 * (tid + FR_T * n)) = vb[n];
                 __syncthreads();
+                if (kb == 0 && round == 0) jac_issue();      // (in flight during the matrix phase)
                 if (stp_c && round == 0 && kb == 0) fr.stamps[45] = wall_clock64();
                 if (tile_ok) {
 #pragma unroll
@@ -912,11 +906,9 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
             if (stp_c && round == 0) fr.stamps[46] = wall_clock64();
             if (tile_ok) {
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int rl = (reg & 3) + 8 * (reg >> 2) + 4 * lhi, slot = 32 * tile_i + rl;
-                    const int sj = min(max((slot - EKF_CAM) / LMD, 0), m - 1);
-                    const int prw = (slot < EKF_CAM) ? slot : (slot < nslots ? lmc[sj] + (slot - EKF_CAM) % LMD : 0);
-                    const float q = (prw == chunk0 + jl + l31) ? (float)ekf_qdiag(prw, fr.dims, fr.nz) : 0.0f;
+                for (int reg = 0; reg < 16; ++reg) {      // (a diagonal entry's row is this lane's column)
+                    const int rl = (reg & 3) + 8 * (reg >> 2) + 4 * lhi;
+                    const float q = ((dmask >> reg) & 1u) ? (float)ekf_qdiag(chunk0 + jl + l31, fr.dims, fr.nz) : 0.0f;
                     pl[(32 * tile_l + rl) * 64 + jl + l31] = (pt[reg] + q) + acc[reg];
                 }
             }
@@ -980,7 +972,6 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
 #pragma unroll
                         for (int r = 0; r < 4; ++r) pt[t2][r] = Pd[(int64_t)prw[r] * ld + chunk0 + 16 * (ct0 + t2) + lc];
                 }
-                if (kb0 == 0 && round == 0) fetch_jacobian();
                 if (kb0 > 0) __syncthreads();
 #pragma unroll
                 for (int n = 0; n < NL; ++n) {
@@ -988,6 +979,7 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
                     *reinterpret_cast<fr_d2*>(sB + 2 * (tid + FR_T * n)) = vb[n];
                 }
                 __syncthreads();
+                if (kb0 == 0 && round == 0) jac_issue();
                 if (tile_ok) {
                     for (int s4 = 0; s4 < (rows >> 2); ++s4) {      // A[i = c][k = g], B[k = g][j = c]
                         const double a = -sA[(4 * s4 + lg) * 64 + 16 * trow + lc];
@@ -1025,7 +1017,11 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
             __syncthreads();
         }
     }
-    if (!fix) fetch_jacobian();
+    // (pipelined mode: requested above, taken only now -- the support rows depend on nothing this launch computes, and
+    // fetched "while the first stage is in flight" the Jacobian made the matrix phase wait ~3 us for the measurement
+    // workgroup; fetched here as a whole it was 1.6 us of polling and bulk on the way to the A chunk)
+    if (!fix) jac_issue();
+    jac_finish();
     __syncthreads();
     FrPre<NB> pre;
     if (fr.stamps && fr.stamps_heavy && chunk == 0 && tid == 0 && NB <= 6) fr.stamps[14] = wall_clock64();
