@@ -62,6 +62,18 @@ __host__ __device__ inline size_t fr_chunk_a_len(int kpad, bool fix, int elem) {
 }
 
 typedef double pf64x4 __attribute__((ext_vector_type(4)));
+// Stores of W / W_sup (read by later launches only): write-through, like the covariance update's (ekf_cov_update.hip) --
+// plain stores leave 1.2 MB of dirty lines for the end of the launch, where the next front kernel waits for them
+// (us per frame pipelined / serial at n=1024, m=32: plain 24.4 / 36.1, write-through 23.9 / 35.6).
+// FR_W_STORE_MODE (experiments): 0 plain, 2 write-through
+#ifndef FR_W_STORE_MODE
+#define FR_W_STORE_MODE 2
+#endif
+template <typename T>
+__device__ __forceinline__ void fr_w_store(T* p, T v) {
+    if (FR_W_STORE_MODE == 2) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
 typedef float fr_f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ void ekf_poll_sleep() { __builtin_amdgcn_s_sleep(4); }
@@ -663,13 +675,13 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
 #pragma unroll
         for (int r = 0; r < 4; ++r) {                   // W rows of block q are final
             const int row = 16 * q + g + 4 * r;
-            wp[(int64_t)row * fr.ldw + col0 + j] = (T)wq[r];
+            fr_w_store(wp + (int64_t)row * fr.ldw + col0 + j, (T)wq[r]);
             if (fr.wdbg) fr.wdbg[(int64_t)row * fr.ldw + col0 + j] = wq[r];
-            if (cslot >= 0) wsup[(int64_t)row * fr.wsup_ld + cslot] = (T)wq[r];
+            if (cslot >= 0) fr_w_store(wsup + (int64_t)row * fr.wsup_ld + cslot, (T)wq[r]);
             for (unsigned long long mm = smask; mm; mm &= mm - 1) {
                 constexpr int LMD = EkfModel<MODEL>::LMD;
                 const int jj = __builtin_ctzll(mm);
-                wsup[(int64_t)row * fr.wsup_ld + EKF_CAM + LMD * jj + sdim] = (T)wq[r];
+                fr_w_store(wsup + (int64_t)row * fr.wsup_ld + EKF_CAM + LMD * jj + sdim, (T)wq[r]);
             }
         }
         // t[i] += (-L_iq) W_q for i > q, at most LG blocks of -L in registers at a time (the whole

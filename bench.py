@@ -284,7 +284,9 @@ def main():
                                                         "command; not measured in this run)"),
                      "algorithmic_bytes_per_launch": algo_bytes,
                      "mean_launch_us": cov_us, "launches_timed": cov_launches,
-                     "timing": "HIP events attached to the dispatch (start/stop time stamps of the kernel itself)",
+                     "timing": "HIP events attached to the dispatch (start/stop time stamps of the kernel itself), in an "
+                               "instrumented repeat of the timed steps in SERIAL order (the kernel alone on the GPU); in the "
+                               "pipelined timed region it runs beside the next frame's front kernel and takes longer (hidden)",
                      "rocprofv3_mean_us": rocprof_us,
                      "residency": ("P is %.0f MB padded: it stays in the 256 MB Infinity Cache between frames, so "
                                    "`achieved` is an algorithmic-bytes rate, not DRAM traffic" % (flt.backend.ld ** 2 * elem / 1e6))
