@@ -80,10 +80,15 @@ __device__ inline void ekf_measure(const double* __restrict__ cam, const double*
 
 // Camera quaternion injection, extended_kalman_filter.py:138-149.
 // mode 0: as written (both arrays read scalar-LAST by SciPy), mode 1: scalar-first.
-__device__ inline void ekf_quat_inject(double q[4], const double err[3], int mode) {
+// (in two halves: the norm of the old quaternion does not depend on the frame's result -- the front kernel takes it
+// before the substitution, off the tail of the launch; same expressions, same bits)
+__device__ inline double ekf_quat_rnorm(const double q[4]) {
+#pragma clang fp contract(off)
+    return 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+}
+__device__ inline void ekf_quat_inject_n(double q[4], double nq, const double err[3], int mode) {
 #pragma clang fp contract(off)      // same bits wherever it is inlined (front kernel, panel kernel, injection kernel)
     double d[4] = {1.0, 0.5 * err[0], 0.5 * err[1], 0.5 * err[2]};
-    const double nq = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     const double nd = 1.0 / sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]);
     double x1, y1, z1, w1, x2, y2, z2, w2;
     if (mode == 0) {
@@ -99,6 +104,9 @@ __device__ inline void ekf_quat_inject(double q[4], const double err[3], int mod
     const double z = w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2;
     const double nr = 1.0 / sqrt(w * w + x * x + y * y + z * z);
     q[0] = w * nr; q[1] = x * nr; q[2] = y * nr; q[3] = z * nr;
+}
+__device__ inline void ekf_quat_inject(double q[4], const double err[3], int mode) {
+    ekf_quat_inject_n(q, ekf_quat_rnorm(q), err, mode);
 }
 
 

@@ -580,6 +580,7 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
         if (col0 == 0)
             for (int i = 0; i < 4; ++i) q_old[i] = fr.state[3 + i];
     }
+    const double q_rn = (MODEL == 0 && col0 == 0) ? ekf_quat_rnorm(q_old) : 0.0;      // (here: not on the tail of the launch)
     double part = 0.0;
     // Prefetch (a chunk that is BEHIND the factorisation -- every chunk in the pipelined sequence mode, whose
     // prologue is longer -- finds everything published already; fetching Dinv / y, then -L, then computing cost two
@@ -739,7 +740,7 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
             if (lane == 0) {
                 double qv[4] = {q_old[0], q_old[1], q_old[2], q_old[3]};
                 const double err[3] = {e0, e1, e2};
-                ekf_quat_inject(qv, err, fr.quat_mode);
+                ekf_quat_inject_n(qv, q_rn, err, fr.quat_mode);
                 for (int i = 0; i < 4; ++i) fr.state[3 + i] = qv[i];
                 for (int i = 0; i < 3; ++i) fr.state[7 + i] = 0.0;   // :152
                 if (fr.traj_row) {

@@ -279,9 +279,9 @@ def test_full_size_properties_n1024_fp32():
 
 @pytest.mark.parametrize("dtype,kernel", [("float64", "mfma"), ("float32", "mfma"), ("float32", "valu")])
 def test_resident_sequence_entry_matches_per_frame_calls(dtype, kernel):
-    """ekf_observe_sequence_device (cross-frame lookahead: priority rows + big update on a
-    second stream) must give BITWISE the results of per-frame observe() calls, also with a
-    landmark detected twice in a frame and with the lookahead switched off."""
+    """ekf_observe_sequence_device (pipelined mode: the front kernel of frame t+1 beside the covariance
+    update of frame t, support entries of P completed inside the front kernel) must give BITWISE the results
+    of per-frame observe() calls, also with a landmark detected twice in a frame and with the mode switched off."""
     import torch
     from aruco_slam_amd.synthetic import SyntheticStream
     outs = []
@@ -315,10 +315,39 @@ def test_resident_sequence_entry_matches_per_frame_calls(dtype, kernel):
             assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("n,m,dtype", [(160, 40, "float32"), (96, 48, "float64"), (48, 16, "float32")])
+def test_pipelined_sequence_mode_beyond_96_rows_is_bitwise_the_serial_order(n, m, dtype):
+    """k = 120 / 144: every row of the factorisation publishes its own blocks (no free wave beyond 6 block columns),
+    two rows per wave; k = 48: the publishing-wave arrangement with three block columns.  Pipelined mode forced on,
+    two calls (odd and even frame counts: the covariance ends in either buffer), one duplicate detection."""
+    import torch
+    from aruco_slam_amd.synthetic import SyntheticStream
+    s = SyntheticStream(n, m, seed=4)
+    boot = list(s.bootstrap())
+    frames = [(ids.copy(), poses.copy()) for ids, poses in s.steady(13)]
+    frames[6][0][3] = frames[6][0][0]
+    idx = torch.tensor(np.stack([f[0] for f in frames]), dtype=torch.int32, device="cuda")
+    z = torch.tensor(np.stack([f[1][:, :3] for f in frames]), dtype=torch.float64, device="cuda")
+    outs = []
+    for mode in (True, False):
+        flt = _ekf(max_landmarks=n, max_visible=m, cov_dtype=dtype, lookahead=mode)
+        for ids, poses in boot:
+            flt.observe(ids, poses)
+        traj = torch.zeros((len(frames), 7), dtype=torch.float64, device="cuda")
+        for lo, hi in ((0, 5), (5, 13)):
+            flt.backend.observe_sequence(idx[lo:hi], z[lo:hi], traj[lo:hi])
+        flt.backend.sync()
+        outs.append((traj.cpu().numpy(), flt.state, flt.uncertainty))
+        del flt
+    assert np.isfinite(outs[0][2]).all()
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+
+
 def test_pipelined_sequence_mode_at_headline_size_is_bitwise_the_serial_order():
     """n=1024, m=32, f32 covariance: the sequence entry point picks the pipelined mode by itself here (front kernel
-    of frame t+1 beside the covariance update of frame t, priority rows by MFMA from the compact support columns,
-    device-side gates between the two streams).  Three calls back to back (join / restart of the pipeline), a
+    of frame t+1 beside the covariance update of frame t on a second covariance buffer, support entries of P completed
+    on the matrix cores from the compact support columns, device-side gates between the two streams).  Three calls back to back (join / restart of the pipeline), a
     duplicate detection and a frame that sees one landmark in every slot; state, covariance and trajectory must be
     the bits of the serial order, and no status bit may be set."""
     import torch
