@@ -330,6 +330,8 @@ __device__ __forceinline__ void fr_role_measure(const EkfFrame& fr, double* sm) 
     double* rsd = sm + fr.k * JC;                       // [kpad]
     int* lmc = reinterpret_cast<int*>(rsd + fr.kpad);
     const int tid = threadIdx.x;
+    // (role-level stamps: the start of each of the last 16 launches, by frame number)
+    if (fr.stamps && !fr.stamps_heavy && tid == 0) fr.stamps[16 + ((long long)fr.seqno & 15)] = wall_clock64();
     // pipelined sequence mode: this launch has started, i.e. everything before it on its stream is complete
     if (fr.la_signal && tid == 0)
         __hip_atomic_store(fr.la_sync, fr.la_signal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
