@@ -11,7 +11,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--cpu-frames 0 ${*:---steps 100 --warmup 10}"
+ARGS="--cpu-frames 0 --burn-in 0 ${*:---steps 100 --warmup 10}"
 echo "$ARGS" > "$OUT/bench_args.txt"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/trace.json" 2> "$OUT/trace.err" || exit 1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/pmc_fetch.json" 2> "$OUT/pmc_fetch.err" || exit 1
