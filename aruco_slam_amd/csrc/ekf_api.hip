@@ -625,12 +625,12 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
     // BESIDE C(t) on the other stream, reads P_t from buf[t & 1] and W_t, and completes the entries it needs itself
     // (S-block workgroups: from the compact support columns W_sup the chunks of F(t) left behind; chunk workgroups:
     // on the matrix cores).  Nothing on the critical path F(t) -> F(t+1) waits for a covariance update.
-    //   stream A (the handle's):  F(0) - F(1) - F(2) - ...
+    //   stream A (the handle's):  F(0) - F(1) - F(2) - ... - F(last) - C(last)
     //   stream B (internal)    :  gate - C(0) - signal - gate - C(1) - signal ...
     // Edges between the streams are ordered on the device (an event pair costs ~13 us per edge):
     //   F(t) complete   -> C(t) may start (it reads W_t and overwrites the buffer F(t) read, P_{t-1}): F(t+1) stores
     //                      "t+1 started" when it starts (it follows F(t) on stream A); a one-wave gate kernel in front
-    //                      of C(t) polls that counter (after the last frame a signal kernel stands in for F(t+1));
+    //                      of C(t) polls that counter (the last update of a call follows its front kernel on stream A);
     //   C(t-1) complete -> F(t+1) may read buf[t & 1] and overwrite W_{t-1}: a one-thread kernel behind C(t-1) bumps a
     //                      second counter; F(t) does not finish before it has seen it (its measurement workgroup polls
     //                      at its end), and F(t+1) follows F(t) on stream A.
@@ -674,24 +674,26 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
         }
         bind_exchange(f, fr);
         if (L.elem == 4) ekf_launch_front<float>(fr, f->stream); else ekf_launch_front<double>(fr, f->stream);
-        if (t + 1 == frames) ekf_launch_signal(sync, base + (uint64_t)frames, f->stream);     // no F(t+1) to say that F(t) is over
-        ekf_launch_gate(sync, base + (uint64_t)t + 1, status, f->big);
         EkfFrame cf = fr;
         cf.cov = cbuf[par];
         cf.cov_out = cbuf[par ^ 1];
-        if (L.elem == 4) ekf_launch_cov_update<float>(cf, 2, f->big); else ekf_launch_cov_update<double>(cf, 2, f->big);
-        // an odd number of frames leaves the covariance in the internal buffer: back into the caller's
-        if (t + 1 == frames && (frames & 1))
-            HIP_TRY(hipMemcpyAsync(f->cov, cbuf[1], (size_t)L.cap * L.cap * L.elem, hipMemcpyDeviceToDevice, f->big));
-        ekf_launch_signal(sync + 1, base + (uint64_t)t + 1, f->big);
+        if (t + 1 < frames) {
+            ekf_launch_gate(sync, base + (uint64_t)t + 1, status, f->big);
+            if (L.elem == 4) ekf_launch_cov_update<float>(cf, 2, f->big); else ekf_launch_cov_update<double>(cf, 2, f->big);
+            ekf_launch_signal(sync + 1, base + (uint64_t)t + 1, f->big);
+        } else {
+            // The LAST update of the call runs on the handle's stream, straight behind its front kernel: stream order says
+            // that F(t) is over, and F(t) did not finish before it had seen C(t-1) complete (its end gate) -- no gate, no
+            // signal, and nothing to join afterwards (4 device-side hops of ~1.2 us per call).  The counters keep the
+            // values of frame t - 1; the next call's waits are for values beyond base + frames, which its own launches set.
+            if (L.elem == 4) ekf_launch_cov_update<float>(cf, 2, f->stream); else ekf_launch_cov_update<double>(cf, 2, f->stream);
+            // an odd number of frames leaves the covariance in the internal buffer: back into the caller's
+            if (frames & 1)
+                HIP_TRY(hipMemcpyAsync(f->cov, cbuf[1], (size_t)L.cap * L.cap * L.elem, hipMemcpyDeviceToDevice, f->stream));
+        }
         HIP_TRY(hipGetLastError());
     }
     f->la_base = base + (uint64_t)frames;
-    // join: everything later on the main stream (and every getter) sees the final covariance -- a gate on stream A
-    // that waits for the last signal of stream B (an event pair costs ~13 us, the gate ~1 us; the kernel boundary
-    // behind the gate gives the memory ordering, as inside the sequence)
-    ekf_launch_gate(sync + 1, base + (uint64_t)frames, status, f->stream);
-    HIP_TRY(hipGetLastError());
     f->last_m = m;
     return EKF_OK;
 }

@@ -136,8 +136,8 @@ int ekf_observe_device(ekf_filter *f, const int32_t *lm_index_dev,
  * the front kernel of frame t+1 completes the few rows of P_{t+1} it reads from P_t and W_t on the
  * fly, with the update's own per-element instruction sequence: results are bitwise those of
  * per-frame ekf_observe calls.  The two streams are ordered by one-wave gate kernels on the
- * device, every wait bounded.  The call returns with the handle's stream waiting for the internal
- * one and the covariance back in the caller's buffer. */
+ * device, every wait bounded.  The last update of a call runs on the handle's stream again, so after the
+ * call that stream alone orders everything that follows, and the covariance is back in the caller's buffer. */
 int ekf_observe_sequence_device(ekf_filter *f, const int32_t *lm_index_dev,
                                 const double *z_dev, int32_t m, int32_t frames,
                                 double *trajectory_dev);
