@@ -133,6 +133,8 @@ struct ekf_filter {
     hipStream_t stream = nullptr;
     hipStream_t big = nullptr;          // internal stream: big covariance update in sequence mode
     hipEvent_t ev_small[2] = {}, ev_big[2] = {};
+    hipEvent_t ev_front = nullptr;      // recorded behind the front part of the last per-frame observe: the state is final there
+    bool front_pending = false;         // ... and nothing that changes the state has been enqueued since
     int device = 0;
     void* cov = nullptr;
     int64_t ld = 0;
@@ -286,6 +288,10 @@ int enqueue_frame(ekf_filter* f, const int32_t* idx_dev, const double* z_dev, in
         if (f32) ekf_launch_panel<float>(fr, f->stream); else ekf_launch_panel<double>(fr, f->stream);
         if (fr.model == 1) ekf_launch_inject_rot(fr, f->n_lm, f->stream);
     }
+    // The state (and the status word) are final here: a state getter that follows waits for this event only and
+    // reads back beside the covariance update (sync_and_check) -- what BaseFilter.process_frame does every frame.
+    f->front_pending = false;
+    if (!f->timing && hipEventRecord(f->ev_front, f->stream) == hipSuccess) f->front_pending = true;
     // the covariance update is timed by its own start / stop time stamps (what rocprofv3 reports), not by
     // events recorded around the launch (those also hold ~4 us of dispatch gap)
     if (f32) ekf_launch_cov_update<float>(fr, variant, f->stream, ev ? ev[3] : nullptr, ev ? ev[4] : nullptr);
@@ -306,10 +312,20 @@ int check_ready(ekf_filter* f) {
 // `state_count` > 0: the first state_count doubles of the state come back with the same synchronisation
 // (f->readback + 256): one stream sync per getter instead of a sync and two blocking copies
 int sync_and_check(ekf_filter* f, int state_count = 0) {
-    HIP_TRY(hipMemcpyAsync(f->readback, f->at<int32_t>(f->lay.off_status), 32, hipMemcpyDeviceToHost, f->stream));
-    if (state_count > 0)
-        HIP_TRY(hipMemcpyAsync(f->readback + 256, f->state, (size_t)state_count * 8, hipMemcpyDeviceToHost, f->stream));
-    HIP_TRY(hipStreamSynchronize(f->stream));
+    if (state_count > 0 && f->front_pending) {
+        // State getter right after a per-frame observe: the state and the status word were final when the front part
+        // of that frame ended; the covariance update behind it goes on while the host reads back (internal stream: idle
+        // outside ekf_observe_sequence_device, ordered here by the host having seen the event) and prepares the next frame.
+        HIP_TRY(hipEventSynchronize(f->ev_front));
+        HIP_TRY(hipMemcpyAsync(f->readback, f->at<int32_t>(f->lay.off_status), 32, hipMemcpyDeviceToHost, f->big));
+        HIP_TRY(hipMemcpyAsync(f->readback + 256, f->state, (size_t)state_count * 8, hipMemcpyDeviceToHost, f->big));
+        HIP_TRY(hipStreamSynchronize(f->big));
+    } else {
+        HIP_TRY(hipMemcpyAsync(f->readback, f->at<int32_t>(f->lay.off_status), 32, hipMemcpyDeviceToHost, f->stream));
+        if (state_count > 0)
+            HIP_TRY(hipMemcpyAsync(f->readback + 256, f->state, (size_t)state_count * 8, hipMemcpyDeviceToHost, f->stream));
+        HIP_TRY(hipStreamSynchronize(f->stream));
+    }
     const int32_t st = reinterpret_cast<const int32_t*>(f->readback)[0];
     static const bool ignore = getenv("EKF_IGNORE_NUMERIC") != nullptr;   // timing ablations only
     if (st != 0 && !ignore) {
@@ -395,6 +411,7 @@ int ekf_create(const ekf_config* cfg, ekf_filter** out) {
         return fail(EKF_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
     }
     e = hipStreamCreateWithFlags(&f->big, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_front, hipEventDisableTiming);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
         e = hipEventCreateWithFlags(&f->ev_small[i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_big[i], hipEventDisableTiming);
@@ -425,6 +442,7 @@ int ekf_destroy(ekf_filter* f) {
         if (f->ev_small[i]) (void)hipEventDestroy(f->ev_small[i]);
         if (f->ev_big[i]) (void)hipEventDestroy(f->ev_big[i]);
     }
+    if (f->ev_front) (void)hipEventDestroy(f->ev_front);
     for (auto& e : f->ev) (void)hipEventDestroy(e);
     for (int i = 0; i < kStageSlots; ++i)
         if (f->slot_done[i]) (void)hipEventDestroy(f->slot_done[i]);
@@ -468,6 +486,7 @@ int ekf_reset(ekf_filter* f, const double initial_camera_pose[10]) {
     f->fseq = 0;
     f->done_total = 0;
     f->la_base = 0;
+    f->front_pending = false;
     HIP_TRY(hipMemcpyAsync(f->state, initial_camera_pose, 10 * sizeof(double), hipMemcpyHostToDevice,
                            f->stream));
     // P = 0.1 I_10  (extended_kalman_filter.py:48)
@@ -493,6 +512,7 @@ int ekf_add_markers(ekf_filter* f, const double* cam_frame_xyz, const double* di
     if (f->n_lm + count > f->cfg.max_landmarks)
         return fail(EKF_ERR_CAPACITY, "more landmarks than max_landmarks");
     const Layout& L = f->lay;
+    f->front_pending = false;
     int done = 0;
     while (done < count) {
         const int chunk = std::min(256, count - done);
@@ -694,6 +714,7 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
         HIP_TRY(hipGetLastError());
     }
     f->la_base = base + (uint64_t)frames;
+    f->front_pending = false;
     f->last_m = m;
     return EKF_OK;
 }
@@ -806,6 +827,7 @@ int ekf_set_state(ekf_filter* f, const double* state, int32_t num_landmarks) {
     if (!state || num_landmarks < 0) return fail(EKF_ERR_INVALID, "bad state");
     if (num_landmarks > f->cfg.max_landmarks)
         return fail(EKF_ERR_CAPACITY, "more landmarks than max_landmarks");
+    f->front_pending = false;
     HIP_TRY(hipStreamSynchronize(f->stream));
     HIP_TRY(hipMemset(f->state, 0, (size_t)f->lay.cap * 8));
     HIP_TRY(hipMemcpy(f->state, state, (size_t)(f->lay.lmd * num_landmarks + EKF_CAM) * 8,
