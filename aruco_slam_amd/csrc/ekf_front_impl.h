@@ -814,10 +814,6 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
     };
     T pcr[EKF_CAM];
     T plr[NU][LMD];
-    if (!fix) {
-#pragma unroll
-        for (int a = 0; a < EKF_CAM; ++a) pcr[a] = P[a * ld + c];
-    }
     if (tid < m) lmc[tid] = ekf_lm_column(fr, LMD, tid, false);
     if (fr.wsup && tid >= 64 && tid < 64 + fr.next_m) {     // (the next frame's indices, for the support-column copy of W)
         int ni = fr.next_idx[tid - 64];
@@ -834,6 +830,10 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
         smask_l[tid] = mk;
     }
     if (!fix) {
+        // (camera rows and landmark rows together: requested before the index round trip, the ten camera-row values
+        // were spilled one by one, each load waited for -- hipcc)
+#pragma unroll
+        for (int a = 0; a < EKF_CAM; ++a) pcr[a] = P[a * ld + c];
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const int ju = min(g + NWV * u, m - 1);
