@@ -75,23 +75,30 @@ class EKF_Rotations(BaseFilter):  # noqa: N801  (name of the reference class)
 
     # -- :66-90 ----------------------------------------------------------------
     def observe(self, ids, poses) -> None:
-        ids = [int(i) for i in ids]
+        if isinstance(ids, np.ndarray) and ids.dtype.kind in "iu":
+            ids = ids.reshape(-1).tolist()
+        else:
+            ids = [int(i) for i in ids]
         if not ids:
             raise ValueError("observe() needs at least one detection")
         poses = np.asarray(poses, dtype=np.float64).reshape(len(ids), -1)
-        fresh, new_pose = [], []
-        for idx, pose in zip(ids, poses):
-            if idx in self.landmarks or idx in fresh:
-                continue
-            fresh.append(idx)
-            new_pose.append(pose[:6])
-        if fresh:
+        known = self.landmarks
+        try:                                   # steady state: every marker of the frame is in the map already
+            index = [known[i] for i in ids]
+        except KeyError:
+            fresh, new_pose = [], []
+            for idx, pose in zip(ids, poses):
+                if idx in known or idx in fresh:
+                    continue
+                fresh.append(idx)
+                new_pose.append(pose[:6])
             self._hip.add_markers(np.asarray(new_pose))
             for idx in fresh:
-                self.landmarks[idx] = self.num_landmarks
+                known[idx] = self.num_landmarks
                 self.num_landmarks += 1
+            index = [known[i] for i in ids]
         z = np.hstack((poses[:, XYZ_DIMS], euler_xyz_to_quat(poses[:, 3:6])))      # :216-224
-        self._hip.observe([self.landmarks[i] for i in ids], z)
+        self._hip.observe(index, z)
 
     # -- :275-335 --------------------------------------------------------------
     def add_marker(self, idx, pose, uncertainity=None) -> None:

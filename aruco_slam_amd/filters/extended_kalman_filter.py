@@ -76,23 +76,30 @@ class EKF(BaseFilter):
     def observe(self, ids, poses) -> None:
         """Add unseen markers, predict, update.  ``ids``: iterable of marker
         ids; ``poses``: (m, 6) ``[tvec | rvec]``, only ``pose[0:3]`` is used."""
-        ids = [int(i) for i in ids]
+        if isinstance(ids, np.ndarray) and ids.dtype.kind in "iu":
+            ids = ids.reshape(-1).tolist()     # (what process_frame passes: ids.flatten(), base_filter.py:199)
+        else:
+            ids = [int(i) for i in ids]
         if not ids:
             raise ValueError("observe() needs at least one detection")
         poses = np.asarray(poses, dtype=np.float64).reshape(len(ids), -1)
-        fresh, new_xyz = [], []
-        for idx, pose in zip(ids, poses):
-            if idx in self.landmarks or idx in fresh:
-                continue
-            fresh.append(idx)
-            new_xyz.append(pose[XYZ_DIMS])
-        if fresh:
+        known = self.landmarks
+        try:                                   # steady state: every marker of the frame is in the map already
+            index = [known[i] for i in ids]
+        except KeyError:
+            fresh, new_xyz = [], []
+            for idx, pose in zip(ids, poses):
+                if idx in known or idx in fresh:
+                    continue
+                fresh.append(idx)
+                new_xyz.append(pose[XYZ_DIMS])
             # every add_marker of a frame sees the same (pre-update) camera pose
             self._hip.add_markers(np.asarray(new_xyz))
             for idx in fresh:
-                self.landmarks[idx] = self.num_landmarks
+                known[idx] = self.num_landmarks
                 self.num_landmarks += 1
-        self._hip.observe([self.landmarks[i] for i in ids], poses[:, XYZ_DIMS])
+            index = [known[i] for i in ids]
+        self._hip.observe(index, poses[:, XYZ_DIMS])
 
     # -- :239-290 --------------------------------------------------------------
     def add_marker(self, idx, pose, uncertainity=None) -> None:
