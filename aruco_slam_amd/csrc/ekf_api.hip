@@ -135,6 +135,11 @@ struct ekf_filter {
     hipEvent_t ev_small[2] = {}, ev_big[2] = {};
     hipEvent_t ev_front = nullptr;      // recorded behind the front part of the last per-frame observe: the state is final there
     bool front_pending = false;         // ... and nothing that changes the state has been enqueued since
+    // host mirror of the state (readback + 256) and of "the status word is not zero" (readback + 128), written by the fused
+    // front kernel of a per-frame observe: a state getter is then an event wait and a memcpy
+    bool mirror_fresh = false;          // the last frame wrote the mirror
+    bool mirror_trust = false;          // entries no frame writes (EKF_Rotations: landmark error states) agree with the device
+    bool status_clean = false;          // the device status word was zero when it was last read
     int device = 0;
     void* cov = nullptr;
     int64_t ld = 0;
@@ -225,6 +230,8 @@ EkfFrame make_frame(ekf_filter* f, const int32_t* idx_dev, const double* z_dev, 
     fr.nz = EkfNoise{f->cfg.q_cam, f->cfg.q_err, f->cfg.q_lm, f->cfg.r_uncertainty};
     fr.quat_mode = f->cfg.quat_mode;
     fr.n_lm = f->n_lm;
+    fr.state_host = nullptr;
+    fr.status_host = nullptr;
     return fr;
 }
 
@@ -272,9 +279,16 @@ int enqueue_frame(ekf_filter* f, const int32_t* idx_dev, const double* z_dev, in
     }
     hipEvent_t* ev_all = (ev && !f->timing_cov_only) ? ev : nullptr;
     if (ev_all) HIP_TRY(hipEventRecord(ev[0], f->stream));
+    f->mirror_fresh = false;
     if (use_front_kernel(f, fr)) {
         // one launch: timing slot 0 = the whole front kernel, slots 1 and 2 stay empty
         bind_exchange(f, fr);
+        static const bool no_mirror = getenv("EKF_NO_HOST_MIRROR") != nullptr;     // (experiments)
+        if (!f->timing && !no_mirror) {
+            fr.state_host = reinterpret_cast<double*>(f->readback + 256);
+            fr.status_host = reinterpret_cast<int32_t*>(f->readback + 128);
+            f->mirror_fresh = true;
+        }
         if (f32) ekf_launch_front<float>(fr, f->stream); else ekf_launch_front<double>(fr, f->stream);
         if (ev_all) {
             HIP_TRY(hipEventRecord(ev[1], f->stream));
@@ -317,6 +331,11 @@ int sync_and_check(ekf_filter* f, int state_count = 0) {
         // of that frame ended; the covariance update behind it goes on while the host reads back (internal stream: idle
         // outside ekf_observe_sequence_device, ordered here by the host having seen the event) and prepares the next frame.
         HIP_TRY(hipEventSynchronize(f->ev_front));
+        // ... and if the fused front kernel has written the state into the pinned mirror and nobody has raised a status
+        // bit (their stores to host memory are complete with the kernel), there is nothing to copy at all
+        if (f->mirror_fresh && f->mirror_trust && f->status_clean &&
+            *reinterpret_cast<volatile int32_t*>(f->readback + 128) == 0)
+            return EKF_OK;
         HIP_TRY(hipMemcpyAsync(f->readback, f->at<int32_t>(f->lay.off_status), 32, hipMemcpyDeviceToHost, f->big));
         HIP_TRY(hipMemcpyAsync(f->readback + 256, f->state, (size_t)state_count * 8, hipMemcpyDeviceToHost, f->big));
         HIP_TRY(hipStreamSynchronize(f->big));
@@ -327,6 +346,8 @@ int sync_and_check(ekf_filter* f, int state_count = 0) {
         HIP_TRY(hipStreamSynchronize(f->stream));
     }
     const int32_t st = reinterpret_cast<const int32_t*>(f->readback)[0];
+    f->status_clean = (st == 0);
+    if (state_count == f->dims()) f->mirror_trust = true;      // (a full copy has just refreshed the mirror)
     static const bool ignore = getenv("EKF_IGNORE_NUMERIC") != nullptr;   // timing ablations only
     if (st != 0 && !ignore) {
         // (sticky until ekf_reset: after any of these the filter state is not trustworthy)
@@ -487,6 +508,10 @@ int ekf_reset(ekf_filter* f, const double initial_camera_pose[10]) {
     f->done_total = 0;
     f->la_base = 0;
     f->front_pending = false;
+    std::memset(f->readback, 0, 256 + (size_t)L.cap * 8);      // (the stream is idle: synchronised above)
+    f->mirror_fresh = false;
+    f->mirror_trust = true;        // state and mirror are both zero beyond what frames write
+    f->status_clean = true;
     HIP_TRY(hipMemcpyAsync(f->state, initial_camera_pose, 10 * sizeof(double), hipMemcpyHostToDevice,
                            f->stream));
     // P = 0.1 I_10  (extended_kalman_filter.py:48)
@@ -715,6 +740,7 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
     }
     f->la_base = base + (uint64_t)frames;
     f->front_pending = false;
+    f->status_clean = false;       // (gate kernels raise status bits without the host word)
     f->last_m = m;
     return EKF_OK;
 }
@@ -828,6 +854,7 @@ int ekf_set_state(ekf_filter* f, const double* state, int32_t num_landmarks) {
     if (num_landmarks > f->cfg.max_landmarks)
         return fail(EKF_ERR_CAPACITY, "more landmarks than max_landmarks");
     f->front_pending = false;
+    f->mirror_trust = false;
     HIP_TRY(hipStreamSynchronize(f->stream));
     HIP_TRY(hipMemset(f->state, 0, (size_t)f->lay.cap * 8));
     HIP_TRY(hipMemcpy(f->state, state, (size_t)(f->lay.lmd * num_landmarks + EKF_CAM) * 8,

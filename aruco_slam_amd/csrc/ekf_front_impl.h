@@ -357,7 +357,7 @@ __device__ __forceinline__ void fr_role_measure(const EkfFrame& fr, double* sm) 
     if (fr.la_gate && tid == 0) {
         int it = 0;
         while (__hip_atomic_load(fr.la_sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < fr.la_gate) {
-            if (++it > (1 << 22)) { atomicOr(fr.status, EKF_ST_GATE_TIMEOUT); break; }
+            if (++it > (1 << 22)) { ekf_raise(fr, EKF_ST_GATE_TIMEOUT); break; }
             __builtin_amdgcn_s_sleep(8);
         }
     }
@@ -499,7 +499,7 @@ __device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, double* v_sm)
     int bad = 0, badcol = 0;
     sv_factor<NB>(fr, io, v_sm, bad, badcol);
     if ((bad | io.spin_fail | io.stale) && lane == 0) {
-        atomicOr(fr.status, (bad ? EKF_ST_NOT_SPD : 0) | (io.spin_fail ? EKF_ST_TIMEOUT : 0) | (io.stale ? EKF_ST_STALE_S : 0));
+        ekf_raise(fr, (bad ? EKF_ST_NOT_SPD : 0) | (io.spin_fail ? EKF_ST_TIMEOUT : 0) | (io.stale ? EKF_ST_STALE_S : 0));
         if (bad) {      // diagnostics: which wave saw it, and the first block column
             atomicOr(fr.status + 1, 1 << wave);
             atomicCAS(fr.status + 2, 0, badcol);
@@ -510,7 +510,7 @@ __device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, double* v_sm)
     // been read before its producer had written it: it then counted as "no objection")
     if (tid < 256) {
         const int tc = tid >> 4, i = tid & 15;
-        if (tc <= i && i < NB && fr_tag_stale(ekf_ldc(fr.xs_tag + 16 * tc + i), fr.seqno)) atomicOr(fr.status, EKF_ST_STALE_S);
+        if (tc <= i && i < NB && fr_tag_stale(ekf_ldc(fr.xs_tag + 16 * tc + i), fr.seqno)) ekf_raise(fr, EKF_ST_STALE_S);
     }
 }
 
@@ -735,6 +735,7 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
         if (g == 0 && (col < 3 || (col >= EKF_CAM && col < fr.dims))) {
             nv = st_old + part;
             fr.state[col] = nv;
+            if (fr.state_host) fr.state_host[col] = nv;
         }
         if (col0 == 0) {
             const double e0 = __shfl(part, 7), e1 = __shfl(part, 8), e2 = __shfl(part, 9);
@@ -745,6 +746,10 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
                 ekf_quat_inject_n(qv, q_rn, err, fr.quat_mode);
                 for (int i = 0; i < 4; ++i) fr.state[3 + i] = qv[i];
                 for (int i = 0; i < 3; ++i) fr.state[7 + i] = 0.0;   // :152
+                if (fr.state_host) {
+                    for (int i = 0; i < 4; ++i) fr.state_host[3 + i] = qv[i];
+                    for (int i = 0; i < 3; ++i) fr.state_host[7 + i] = 0.0;
+                }
                 if (fr.traj_row) {
                     fr.traj_row[0] = x0; fr.traj_row[1] = x1; fr.traj_row[2] = x2;
                     for (int i = 0; i < 4; ++i) fr.traj_row[3 + i] = qv[i];
@@ -755,8 +760,8 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
     if (stp) stp[NB] = wall_clock64();
     // the frame tags of the factor's block columns, all at once and after everything that depended on them has been
     // issued (a status bit is all they can raise; checked inside the steps they were a round trip per block column)
-    if (wv == 0 && lane < NB && fr_tag_stale(ekf_ldc(fr.xl + fr.xl_tag + 1 + lane), fr.seqno)) atomicOr(fr.status, EKF_ST_STALE_COL);
-    if (wv == 0 && lane == NB && fr_tag_stale(ekf_ldc(fr.xl + fr.xl_tag), fr.seqno)) atomicOr(fr.status, EKF_ST_STALE_JAC);
+    if (wv == 0 && lane < NB && fr_tag_stale(ekf_ldc(fr.xl + fr.xl_tag + 1 + lane), fr.seqno)) ekf_raise(fr, EKF_ST_STALE_COL);
+    if (wv == 0 && lane == NB && fr_tag_stale(ekf_ldc(fr.xl + fr.xl_tag), fr.seqno)) ekf_raise(fr, EKF_ST_STALE_JAC);
 }
 
 template <typename T, int NU, int MODEL, int NB>
@@ -808,9 +813,9 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
                 hs[e] = v;
             }
         }
-        if (spin) atomicOr(fr.status, EKF_ST_TIMEOUT);
+        if (spin) ekf_raise(fr, EKF_ST_TIMEOUT);
         if (fr.stamps && fr.stamps_heavy && chunk == 0 && tid == 0 && NB <= 6) fr.stamps[44] = wall_clock64();
-        if (tid == 0 && fr_tag_stale(jtag, fr.seqno)) atomicOr(fr.status, EKF_ST_STALE_JAC);
+        if (tid == 0 && fr_tag_stale(jtag, fr.seqno)) ekf_raise(fr, EKF_ST_STALE_JAC);
     };
     T pcr[EKF_CAM];
     T plr[NU][LMD];
@@ -1084,7 +1089,7 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
     if (g < 4) {
         const int lane = tid & 63, col0 = chunk0 + 16 * g;
         fr_panel<T, NB, MODEL>(fr, a_lds, ekf_lds_flags(flag + 1), pshare, g, col0, lane, spin_fail, pre);
-        if (spin_fail && (tid & 63) == 0) atomicOr(fr.status, EKF_ST_TIMEOUT);
+        if (spin_fail && (tid & 63) == 0) ekf_raise(fr, EKF_ST_TIMEOUT);
     }
     if (MODEL == 0) return;
     // ---- EKF_Rotations: dx of this chunk has to be in memory before the chunk counts as done;
@@ -1112,6 +1117,13 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
         const double x0 = st[0] + ekf_ldc(dx + 0), x1 = st[1] + ekf_ldc(dx + 1), x2 = st[2] + ekf_ldc(dx + 2);
         st[0] = x0; st[1] = x1; st[2] = x2;
         for (int e = 0; e < 4; ++e) st[3 + e] = q[e];
+        if (fr.state_host) {      // (landmark error states are never written: zero in the mirror as on the device)
+            double* sh = fr.state_host + c0;
+            sh[0] = x0; sh[1] = x1; sh[2] = x2;
+            for (int e = 0; e < 4; ++e) sh[3 + e] = q[e];
+            if (i == 0)
+                for (int e = 0; e < 3; ++e) sh[7 + e] = 0.0;
+        }
         if (i == 0) {
             for (int e = 0; e < 3; ++e) st[7 + e] = 0.0;
             if (fr.traj_row) {

@@ -96,7 +96,18 @@ struct EkfFrame {
     unsigned long long done_target;    // value of done_ctr once this frame's last chunk is done
     int32_t xl_tag;                    // frame tags inside xl ([0] Jacobian, [1 + q] block column q, [16] residual): integrity check
     double seqno;                      // this frame's tag (fused frames since reset, from 1)
+    // Per-frame host boundary (ekf_observe + a state getter every frame): the injection code of the fused front kernel
+    // also writes the new state into pinned HOST memory, and whoever raises a status bit also sets a word there, so
+    // that the getter is a wait for the front kernel's event and a memcpy -- no device-to-host copies (null: off).
+    double* state_host;
+    int32_t* status_host;
 };
+
+// raise sticky status bits (and tell the host mirror, if there is one, that the status word is no longer zero)
+__device__ __forceinline__ void ekf_raise(const EkfFrame& fr, int bits) {
+    atomicOr(fr.status, bits);
+    if (fr.status_host) __hip_atomic_store(fr.status_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // First state column of detection j.  Indices that arrive through the device-pointer entry points
 // cannot be checked on the host: an index outside [0, n_lm) is clamped to 0 (so that nothing is read
@@ -105,7 +116,7 @@ struct EkfFrame {
 __device__ __forceinline__ int ekf_lm_column(const EkfFrame& fr, int lmd, int j, bool flag) {
     int i = fr.idx[j];
     if ((unsigned)i >= (unsigned)fr.n_lm) {
-        if (flag) atomicOr(fr.status, EKF_ST_BAD_INDEX);
+        if (flag) ekf_raise(fr, EKF_ST_BAD_INDEX);
         i = 0;
     }
     return EKF_CAM + lmd * i;

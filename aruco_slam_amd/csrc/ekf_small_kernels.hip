@@ -193,7 +193,7 @@ __global__ __launch_bounds__(SV_T) void ekf_solve_kernel(EkfFrame fr) {
     SvIoPlain io{fr};
     int bad = 0, badcol = 0;
     sv_factor<NB>(fr, io, v_sm, bad, badcol);
-    if (bad && (threadIdx.x & 63) == 0) atomicOr(fr.status, EKF_ST_NOT_SPD);
+    if (bad && (threadIdx.x & 63) == 0) ekf_raise(fr, EKF_ST_NOT_SPD);
 }
 
 template <int NB>

@@ -144,8 +144,8 @@ int ekf_observe_sequence_device(ekf_filter *f, const int32_t *lm_index_dev,
 
 /* EKF.get_poses / get_lm_uncertainties (extended_kalman_filter.py:84-93).
  * Synchronise and copy to host.  ekf_get_camera / ekf_get_state directly after ekf_observe / ekf_observe_device wait
- * for the part of that frame that produces the state (and the status word) only; the covariance update of the frame may
- * still be running when they return.  ekf_get_cov_diag / ekf_get_cov / ekf_sync wait for everything. */
+ * for the part of that frame that produces the state (and the status word) only -- the front kernel leaves the state in a
+ * pinned host mirror, so nothing is copied -- and the covariance update of the frame may still be running when they return.  ekf_get_cov_diag / ekf_get_cov / ekf_sync wait for everything. */
 int ekf_get_camera(ekf_filter *f, double out[10]);
 int ekf_get_state(ekf_filter *f, double *out, int32_t count);
 int ekf_get_cov_diag(ekf_filter *f, double *out, int32_t count);

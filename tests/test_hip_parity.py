@@ -836,6 +836,31 @@ def test_stage_and_fused_frames_alternate_inside_one_filter(make, n, m, dtype):
     assert np.array_equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("make", ["_ekf", "_rot"])
+def test_state_getter_after_observe_reads_the_host_mirror_of_the_device_state(make):
+    """A state getter that directly follows a per-frame observe waits for the front part of the frame only and takes the
+    state from the pinned host mirror the injection code writes (no device-to-host copy): it must be the device's state,
+    bit for bit -- also right after new markers (slow path, then mirror again), for both filters, and the covariance
+    getter behind it must see the finished update."""
+    import torch
+    from aruco_slam_amd.synthetic import SyntheticStream
+    rot = make == "_rot"
+    n, m = (40, 8)
+    flt = (_rot if rot else _ekf)(max_landmarks=n, max_visible=m, cov_dtype="float32")
+    s = SyntheticStream(n, m, seed=11, rvec_sigma=0.05 if rot else 0.0)
+    frames = list(s.bootstrap()) + list(s.steady(6))
+    for ids, poses in frames:
+        flt.observe(ids, poses)
+        got = flt.state                                   # (event wait + mirror, or the copy path after add_markers)
+        torch.cuda.synchronize()
+        dev = flt.backend.state_t[:got.size].cpu().numpy()
+        assert np.array_equal(got, dev)
+        cam, marks = flt.get_poses()
+        assert np.array_equal(np.concatenate([cam, marks.reshape(-1)]), dev)
+    p = flt.uncertainty
+    assert np.array_equal(p, p.T) and np.isfinite(p).all()
+
+
 def test_device_resident_bad_index_is_clamped_and_reported():
     """ekf_observe_device / ekf_observe_sequence_device cannot range-check resident indices on the host:
     the kernels clamp them (no out-of-bounds access) and the next synchronising call returns
