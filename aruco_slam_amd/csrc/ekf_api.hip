@@ -598,8 +598,16 @@ int ekf_observe(ekf_filter* f, const int32_t* lm_index, const double* z, int32_t
     // one copy: the pinned slot mirrors the device staging layout [indices, padded to 256 B | z]
     static_assert(sizeof(int32_t) == 4, "layout");
     if (L.off_z - L.off_idx != align256((size_t)f->cfg.max_visible * 4)) return fail(EKF_ERR_STATE, "staging layout");
-    HIP_TRY(hipMemcpyAsync(f->at<char>(L.off_idx), slot, (L.off_z - L.off_idx) + zb, hipMemcpyHostToDevice, f->stream));
-    rc = enqueue_frame(f, f->at<int32_t>(L.off_idx), f->at<double>(L.off_z), m, nullptr);
+    // The kernels read the frame's detections (128 + 768 bytes at m = 32) straight from the pinned slot: a host-to-device
+    // copy in front of them costs more (API call + DMA start, ~8 us before the front kernel begins) than the PCIe reads
+    // cost the kernel's first round trip.  The slot is not reused before this frame's event (64-slot ring).
+    // EKF_COPY_DETECTIONS (experiments): the staged copy instead.
+    static const bool staged = getenv("EKF_COPY_DETECTIONS") != nullptr;
+    if (staged) {
+        HIP_TRY(hipMemcpyAsync(f->at<char>(L.off_idx), slot, (L.off_z - L.off_idx) + zb, hipMemcpyHostToDevice, f->stream));
+        rc = enqueue_frame(f, f->at<int32_t>(L.off_idx), f->at<double>(L.off_z), m, nullptr);
+    } else
+        rc = enqueue_frame(f, hidx, hz, m, nullptr);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(f->slot_done[f->slot], f->stream));
     f->slot = (f->slot + 1) % kStageSlots;

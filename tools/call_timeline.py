@@ -8,7 +8,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 K, W = int(sys.argv[2]), int(sys.argv[3])
 fronts = [i for i, r in enumerate(rows) if "ekf_front_kernel" in r["Kernel_Name"]]
 # front kernels in launch order: bootstrap (one per frame), warm-up call (W), timed call (K), then the instrumented repeats
-boot = len(fronts) - (W + 3 * K) - 40          # (bench.py: 40 host-boundary frames at the end)
+boot = len(fronts) - (W + 3 * K) - 250         # (bench.py: 250 host-boundary frames at the end)
 first = fronts[boot + W]
 last_front = fronts[boot + W + K - 1]
 t0 = int(rows[first]["Start_Timestamp"])
