@@ -77,7 +77,7 @@ Layout make_layout(const ekf_config& c) {
     // pipelined sequence mode (MFMA update, fused front kernel): the second covariance buffer
     // (P_t is read, P_{t+1} written elsewhere, so that the next front kernel can read P_t beside the update)
     L.has_cov2 = c.cov_kernel != EKF_COVK_VALU && (c.flags & 5) == 0 &&
-                 ((c.flags & 2) != 0 || L.cap >= 640);
+                 ((c.flags & 2) != 0 || L.cap >= 256);
     L.off_cov2 = L.has_cov2 ? take((size_t)L.cap * L.cap * L.elem) : 0;
     L.off_wdbg = take((size_t)L.kmax * L.cap * 8);
     L.off_idx = take((size_t)c.max_visible * 4);
@@ -636,13 +636,15 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
     // Pipelined mode (F(t+1) beside C(t), see below): flags bit 1 forces it, bit 0 forbids it, otherwise it is
     // chosen where it was measured to win (tools/pipeline_sweep.py).  MFMA covariance update (f32 or f64) and the
     // fused front kernel only.
-    // (tools/pipeline_sweep.py, us per frame pipelined / serial: n=256 m=16 16.8 / 20.3 - n=512 m=16 21.1 / 21.1 -
-    // n=512 m=32 25.9 / 30.6 - n=1024 m=32 27.8 / 38.6 - n=1024 m=64 115 / 133 - n=2048 m=32 62.8 / 72.9 -
-    // n=2048 m=64 134 / 187 - n=3072 m=64 247 / 298 - n=4096 m=32 240 / 247 - n=4096 m=64 474 / 443: there the front
-    // kernel's 273 workgroups hold every CU while they wait for the factorisation, and the update cannot run beside them)
+    // (tools/pipeline_sweep.py, us per frame pipelined / serial: n=64 m=8 12.9 / 18.5 - n=128 m=8 18.2 / 18.2 -
+    // n=128 m=16 15.3 / 21.2 - n=256 m=16 15.1 / 21.0 - n=512 m=16 15.0 / 22.0 - n=512 m=32 22.8 / 31.1 -
+    // n=1024 m=32 24.2 / 38.9 - n=1024 m=64 110 / 132 - n=2048 m=32 62.4 / 71.9 - n=2048 m=64 126 / 187 -
+    // n=4096 m=32 238 / 249 - n=4096 m=64 468 / 442: there the front kernel's 273 workgroups hold every CU while they
+    // wait for the factorisation, and the update cannot run beside them; f64: n=64 m=8 13.2 / 18.8 - n=256 m=16 16.3 / 21.7
+    // - n=1024 m=32 44.4 / 54.7)
     const int dims_now = f->dims();
     const int kpad_now = (int)round_up(f->lay.rd * m, EKF_RB);
-    const bool auto_on = dims_now >= 700 && !(dims_now > 9000 && kpad_now > 96);
+    const bool auto_on = dims_now >= 200 && !(dims_now > 9000 && kpad_now > 96);
     const bool want = (f->cfg.flags & 2) != 0 || ((f->cfg.flags & 1) == 0 && auto_on);
     bool pipelined = want && f->lay.has_cov2 && !f->timing && frames >= 2 && (f->cfg.flags & 4) == 0;
     if (pipelined && f->la_ok < 0) {

@@ -301,7 +301,7 @@ def main():
                               "steady-state throughput and the GPU's clocks need tens of ms of load to reach their sustained "
                               "level (20 steps per call: 35.5k updates/s without, 37.5k with)",
                    "front": "stage kernels" if args.unfused else "fused front kernel",
-                   "sequence_mode": {"auto": "pipelined where it wins (N >= 700 except N > 9000 with k > 96: "
+                   "sequence_mode": {"auto": "pipelined where it wins (N >= 200 except N > 9000 with k > 96: "
                                              "front kernel of frame t+1 beside the covariance update of frame t, "
                                              "covariance ping-pong between two buffers), else serial",
                                      "on": "pipelined", "off": "serial"}[args.lookahead]},

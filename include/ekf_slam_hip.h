@@ -67,7 +67,7 @@ typedef struct ekf_config {
     int32_t reserved;
     int32_t flags;          /* bits 0-1: pipelined mode of ekf_observe_sequence_device (the front kernel of frame t+1 runs
                              * beside the covariance update of frame t; same results, bit for bit): 0 = chosen by size
-                             * (MFMA covariance update only, either dtype; on from 700 state dimensions, except
+                             * (MFMA covariance update only, either dtype; on from 200 state dimensions, except
                              * above 9000 with more than 32 detections per frame), bit 0 = never, bit 1 = always.  Unless bit 0
                              * is set, a capable configuration adds a second covariance buffer to the workspace.
                              * bit 2: run gather / solve / panel as three separate launches instead of the fused front

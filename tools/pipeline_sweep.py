@@ -4,8 +4,8 @@ sys.path.insert(0, ".")
 from aruco_slam_amd.filters.extended_kalman_filter import EKF
 from aruco_slam_amd.synthetic import SyntheticStream
 INIT = np.array([0, 0, 0, 1, 0, 0, 0, 0, 0, 0])
-for n, m, dtype, nfr in [(256, 16, "float32", 2000), (512, 16, "float32", 2000), (512, 32, "float32", 2000), (1024, 32, "float32", 2000), (1024, 64, "float32", 1000),
-                         (2048, 32, "float32", 600), (2048, 64, "float32", 600), (4096, 64, "float32", 200), (4096, 32, "float32", 200), (1024, 32, "float64", 500), (256, 16, "float64", 2000)]:
+for n, m, dtype, nfr in [(64, 8, "float32", 3000), (128, 8, "float32", 3000), (128, 16, "float32", 3000), (192, 16, "float32", 3000), (256, 16, "float32", 2000), (512, 16, "float32", 2000), (512, 32, "float32", 2000), (1024, 32, "float32", 2000), (1024, 64, "float32", 1000),
+                         (2048, 32, "float32", 600), (2048, 64, "float32", 600), (4096, 64, "float32", 200), (4096, 32, "float32", 200), (1024, 32, "float64", 500), (256, 16, "float64", 2000), (128, 16, "float64", 3000), (64, 8, "float64", 3000)]:
     s = SyntheticStream(n, m, seed=5)
     boot = list(s.bootstrap()); frames = list(s.steady(nfr))
     idx = torch.tensor(np.stack([f[0] for f in frames]), dtype=torch.int32, device="cuda")
