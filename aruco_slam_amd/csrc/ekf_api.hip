@@ -33,6 +33,11 @@ inline int64_t round_up(int64_t v, int64_t q) { return (v + q - 1) / q * q; }
 inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
 constexpr int kStageSlots = 64;   // pinned host ring for ekf_observe
+#ifndef EKF_MACRO_SUPER
+#define EKF_MACRO_SUPER 8
+#endif
+constexpr int kMacroSuper = EKF_MACRO_SUPER;    // macro-tile covariance update: super-tiles of 8 x 8 macro tiles per XCD (ekf_cov_macro.hip)
+constexpr int kMacroMinTiles = 1024;   // ... chosen from this many 128 x 128 tiles of the lower triangle (4 per CU)
 constexpr int kTimedKernels = 4;
 constexpr int kEventPool = 2048;  // frames of timing events kept before folding
 
@@ -42,10 +47,12 @@ struct Layout {
     int kmax;         // rd * max_visible rounded up to 16
     size_t elem;      // sizeof(cov element)
     size_t off_jac, off_resid, off_y, off_lmcol, off_amat, off_sblk, off_lmat, off_dinv, off_lop, off_dop, off_wpanel, off_wpanel2, off_cov2, off_wdbg,
-        off_idx, off_z, off_status, off_stamps, off_dx, off_diag, off_xyz, off_unc,
+        off_idx, off_z, off_status, off_stamps, off_covstats, off_dx, off_diag, off_xyz, off_unc,
         off_xl, off_done, off_sync, off_wsup, total;
     int wsup_ld;      // row length of the compact support-column copy of W (pipelined sequence mode; two copies, by frame parity)
     bool has_cov2;
+    size_t off_tiles; // launch order of the macro-tile covariance update (f32, large problems)
+    int tiles_cap;    // entries
     // fused front kernel: one exchange buffer per fused-frame parity (offsets / length in doubles)
     size_t xl_len, xl_dop, xl_y, xl_jac, xl_tag, xl_xs, xl_xr, xl_stag;
 };
@@ -84,6 +91,7 @@ Layout make_layout(const ekf_config& c) {
     L.off_z = take((size_t)c.max_visible * 7 * 8);
     L.off_status = take(256);
     L.off_stamps = take(64 * 8);
+    L.off_covstats = take(32 * 8);
     L.off_dx = take((size_t)L.cap * 8);
     L.off_diag = take((size_t)L.cap * 8);
     L.off_xyz = take((size_t)256 * 6 * 8);
@@ -104,6 +112,13 @@ Layout make_layout(const ekf_config& c) {
         L.wsup_ld = (int)round_up(EKF_CAM + (int64_t)L.lmd * c.max_visible, 32);
         L.off_wsup = take((size_t)2 * L.kmax * L.wsup_ld * L.elem);
     }
+    {
+        // (the grid is 8 x the longest per-XCD list: the tile count plus, at worst, one super-tile per XCD)
+        const int tmax = (int)(L.cap / 128);
+        L.tiles_cap = (L.elem == 4 && c.cov_kernel != EKF_COVK_VALU && c.cov_kernel != EKF_COVK_MFMA_TILE)
+                          ? tmax * (tmax + 1) / 2 + 8 * kMacroSuper * kMacroSuper : 0;
+        L.off_tiles = take((size_t)L.tiles_cap * 4);
+    }
     L.total = o;
     return L;
 }
@@ -119,8 +134,10 @@ int check_config(const ekf_config* c) {
         return fail(EKF_ERR_INVALID, "cov_dtype must be EKF_COV_F64 or EKF_COV_F32");
     if (c->quat_mode != EKF_QUAT_AS_WRITTEN && c->quat_mode != EKF_QUAT_SCALAR_FIRST)
         return fail(EKF_ERR_INVALID, "unknown quat_mode");
-    if (c->cov_kernel < EKF_COVK_AUTO || c->cov_kernel > EKF_COVK_MFMA)
+    if (c->cov_kernel < EKF_COVK_AUTO || c->cov_kernel > EKF_COVK_MFMA_MACRO)
         return fail(EKF_ERR_INVALID, "unknown cov_kernel");
+    if (c->cov_kernel == EKF_COVK_MFMA_MACRO && c->cov_dtype != EKF_COV_F32)
+        return fail(EKF_ERR_INVALID, "EKF_COVK_MFMA_MACRO exists for the f32 covariance only");
     if (!(c->r_uncertainty > 0.0)) return fail(EKF_ERR_INVALID, "r_uncertainty must be > 0");
     return EKF_OK;
 }
@@ -155,6 +172,9 @@ struct ekf_filter {
     uint64_t done_total = 0;   // column chunks of fused frames enqueued since reset
     uint64_t la_base = 0;      // frames that went through the pipelined sequence mode since reset (device counters)
     int la_ok = -1;            // pipelined mode usable (-1: not probed yet; 0: the two streams share a hardware queue)
+    // macro-tile covariance update: launch-order table in the workspace, rebuilt when the tile count changes
+    int tiles_T = -1, tiles_grid = 0;
+    uint32_t* tiles_host = nullptr;     // pinned staging copy
     // pinned staging ring for host-pointer observes
     char* pinned = nullptr;
     size_t slot_bytes = 0;
@@ -232,6 +252,13 @@ EkfFrame make_frame(ekf_filter* f, const int32_t* idx_dev, const double* z_dev, 
     fr.n_lm = f->n_lm;
     fr.state_host = nullptr;
     fr.status_host = nullptr;
+    fr.cov_tiles = nullptr;
+    fr.cov_grid = 0;
+    fr.cov_stats = f->debug_stamps ? f->at<unsigned long long>(L.off_covstats) : nullptr;
+    if (f->tiles_T > 0 && f->tiles_T == (fr.dims + 127) / 128) {
+        fr.cov_tiles = f->at<uint32_t>(L.off_tiles);
+        fr.cov_grid = f->tiles_grid;
+    }
     return fr;
 }
 
@@ -262,9 +289,34 @@ void bind_exchange(ekf_filter* f, EkfFrame& fr) {
     f->fseq++;
 }
 
+// Macro-tile covariance update (f32, large problems: ekf_cov_macro.hip): chosen from kMacroMinTiles tiles of 128 x 128
+// (or forced); its launch-order table depends on the tile count only and is rebuilt -- synchronously: this happens when
+// landmarks are added, a few dozen times in the life of a filter -- whenever that changes.
+int ensure_tiles(ekf_filter* f) {
+    const Layout& L = f->lay;
+    const int T = (f->dims() + 127) / 128;
+    const bool want = L.tiles_cap > 0 &&
+                      (f->cfg.cov_kernel == EKF_COVK_MFMA_MACRO || T * (T + 1) / 2 >= kMacroMinTiles);
+    if (!want) {
+        f->tiles_T = -1;
+        return EKF_OK;
+    }
+    if (f->tiles_T == T) return EKF_OK;
+    HIP_TRY(hipStreamSynchronize(f->stream));
+    HIP_TRY(hipStreamSynchronize(f->big));
+    const int grid = ekf_cov_macro_table(T, kMacroSuper, f->tiles_host, L.tiles_cap);
+    if (grid <= 0) return fail(EKF_ERR_STATE, "macro-tile launch table does not fit the workspace");
+    HIP_TRY(hipMemcpy(f->at<uint32_t>(L.off_tiles), f->tiles_host, (size_t)grid * 4, hipMemcpyHostToDevice));
+    f->tiles_T = T;
+    f->tiles_grid = grid;
+    return EKF_OK;
+}
+
 // predict + update for one frame: the front kernel (or gather / solve / panel) and the covariance update
 int enqueue_frame(ekf_filter* f, const int32_t* idx_dev, const double* z_dev, int m,
                   double* traj_row) {
+    int trc = ensure_tiles(f);
+    if (trc) return trc;
     EkfFrame fr = make_frame(f, idx_dev, z_dev, m, traj_row);
     const bool f32 = f->cfg.cov_dtype == EKF_COV_F32;
     const int variant = f->cfg.cov_kernel == EKF_COVK_VALU ? 1 : 2;
@@ -431,6 +483,13 @@ int ekf_create(const ekf_config* cfg, ekf_filter** out) {
         ekf_destroy(f);
         return fail(EKF_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
     }
+    if (f->lay.tiles_cap > 0) {
+        e = hipHostMalloc(reinterpret_cast<void**>(&f->tiles_host), (size_t)f->lay.tiles_cap * 4, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            ekf_destroy(f);
+            return fail(EKF_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+        }
+    }
     e = hipStreamCreateWithFlags(&f->big, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_front, hipEventDisableTiming);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
@@ -469,6 +528,7 @@ int ekf_destroy(ekf_filter* f) {
         if (f->slot_done[i]) (void)hipEventDestroy(f->slot_done[i]);
     if (f->pinned) (void)hipHostFree(f->pinned);
     if (f->readback) (void)hipHostFree(f->readback);
+    if (f->tiles_host) (void)hipHostFree(f->tiles_host);
     delete f;
     return EKF_OK;
 }
@@ -488,6 +548,7 @@ int ekf_bind_buffers(ekf_filter* f, void* cov_dev, int64_t ld, double* state_dev
     f->ws = static_cast<char*>(workspace_dev);
     f->bound = true;
     f->is_reset = false;
+    f->tiles_T = -1;
     return EKF_OK;
 }
 
@@ -507,6 +568,7 @@ int ekf_reset(ekf_filter* f, const double initial_camera_pose[10]) {
     f->fseq = 0;
     f->done_total = 0;
     f->la_base = 0;
+    f->tiles_T = -1;               // (the workspace, the table with it, has just been cleared)
     f->front_pending = false;
     std::memset(f->readback, 0, 256 + (size_t)L.cap * 8);      // (the stream is idle: synchronised above)
     f->mirror_fresh = false;
@@ -693,6 +755,8 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
     // Every wait is bounded.  The front kernel claims (almost) all LDS of its CUs while its grid is small, so the
     // covariance update's workgroups run on the other CUs instead of next to the pivot chain.
     const Layout& L = f->lay;
+    rc = ensure_tiles(f);
+    if (rc) return rc;
     void* wbuf[2] = {f->at<void>(L.off_wpanel), f->at<void>(L.off_wpanel2)};
     void* cbuf[2] = {f->cov, f->at<void>(L.off_cov2)};
     char* wsup0 = f->at<char>(L.off_wsup);
@@ -983,6 +1047,15 @@ int ekf_debug_fetch(ekf_filter* f, int32_t what, double* out, size_t count) {
                 long long st[64];
                 HIP_TRY(hipMemcpy(st, f->at<long long>(L.off_stamps), sizeof(st), hipMemcpyDeviceToHost));
                 for (int i = 0; i < 64; ++i) out[i] = (double)st[i];
+            }
+            return EKF_OK;
+        case 6:      // counters of the macro-tile covariance update (diagnostic builds only), then cleared
+            if (count < 32) return fail(EKF_ERR_INVALID, "out too small");
+            {
+                unsigned long long st[32];
+                HIP_TRY(hipMemcpy(st, f->at<unsigned long long>(L.off_covstats), sizeof(st), hipMemcpyDeviceToHost));
+                for (int i = 0; i < 32; ++i) out[i] = (double)st[i];
+                HIP_TRY(hipMemset(f->at<unsigned long long>(L.off_covstats), 0, sizeof(st)));
             }
             return EKF_OK;
         default:

@@ -403,6 +403,8 @@ template <>
 void ekf_launch_cov_update<float>(const EkfFrame& fr, int variant, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     if (variant == 1) {
         EKF_COV_LAUNCH(ekf_cov_update_valu<float>, dim3(fr.ncols / 64, fr.ncols / 64), dim3(256), s, e0, e1, fr);
+    } else if (fr.cov_tiles) {
+        ekf_launch_cov_update_macro(fr, s, e0, e1);      // large problems: one workgroup per 128 x 128 macro tile
     } else {
         const int items = ekf_tri_items(fr);
         const dim3 grid((items + 3) / 4), block(256);

@@ -101,6 +101,11 @@ struct EkfFrame {
     // that the getter is a wait for the front kernel's event and a memcpy -- no device-to-host copies (null: off).
     double* state_host;
     int32_t* status_host;
+    // Large problems (f32 covariance): launch order of the 128 x 128 macro-tile covariance update (ekf_cov_macro.hip):
+    // tile (I << 16 | J) of block b, 0xFFFFFFFF = none; null: the wave-per-tile kernel (ekf_cov_update.hip)
+    const uint32_t* cov_tiles;
+    int32_t cov_grid;
+    unsigned long long* cov_stats;     // diagnostics of the macro-tile kernel (builds with CM_STAMPS only; else unused)
 };
 
 // raise sticky status bits (and tell the host mirror, if there is one, that the status word is no longer zero)
@@ -131,6 +136,11 @@ template <typename T> void ekf_launch_panel(const EkfFrame& fr, hipStream_t s);
 // e0 / e1 (optional): events that receive the kernel's own start / stop time stamps (hipExtLaunchKernelGGL)
 template <typename T> void ekf_launch_cov_update(const EkfFrame& fr, int variant, hipStream_t s,
                                                  hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+// f32, large problems: one workgroup per 128 x 128 macro tile, launch order fr.cov_tiles / fr.cov_grid (ekf_cov_macro.hip)
+void ekf_launch_cov_update_macro(const EkfFrame& fr, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+// launch order for T x T macro tiles (lower triangle), super-tiles of S x S dealt to the 8 XCDs: returns the grid size
+// (out == nullptr: only that), -1 if it exceeds `capacity` entries
+int ekf_cov_macro_table(int T, int S, uint32_t* out, int capacity);
 // pipelined sequence mode: one-wave kernels that order the two streams on the device
 void ekf_launch_gate(unsigned long long* counter, unsigned long long target, int32_t* status, hipStream_t s,
                      int max_polls = 1 << 22);

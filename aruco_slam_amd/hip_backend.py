@@ -17,7 +17,7 @@ from ._build import LIB_PATH
 
 EKF_COV_F64, EKF_COV_F32 = 0, 1
 EKF_QUAT_AS_WRITTEN, EKF_QUAT_SCALAR_FIRST = 0, 1
-EKF_COVK_AUTO, EKF_COVK_VALU, EKF_COVK_MFMA = 0, 1, 2
+EKF_COVK_AUTO, EKF_COVK_VALU, EKF_COVK_MFMA, EKF_COVK_MFMA_TILE, EKF_COVK_MFMA_MACRO = 0, 1, 2, 3, 4
 
 # every symbol include/ekf_slam_hip.h declares
 EXPORTED_SYMBOLS = (
@@ -148,7 +148,8 @@ class HipEkf:
         cfg.cov_dtype = {"float64": EKF_COV_F64, "float32": EKF_COV_F32}[str(cov_dtype)]
         cfg.quat_mode = {"as_written": EKF_QUAT_AS_WRITTEN,
                          "scalar_first": EKF_QUAT_SCALAR_FIRST}[quat_mode]
-        kern = {"auto": EKF_COVK_AUTO, "valu": EKF_COVK_VALU, "mfma": EKF_COVK_MFMA}
+        kern = {"auto": EKF_COVK_AUTO, "valu": EKF_COVK_VALU, "mfma": EKF_COVK_MFMA, "mfma_tile": EKF_COVK_MFMA_TILE,
+                "mfma_macro": EKF_COVK_MFMA_MACRO}
         cfg.cov_kernel = kern[cov_kernel]
         cfg.flags = {None: 0, False: 1, True: 2}[lookahead]   # None: pipelined sequence mode where it wins (by size); False: never; True: always
         if not fused:
@@ -301,8 +302,8 @@ class HipEkf:
         rd = self.rows_per_detection
         k, kp, n = rd * m, -(-rd * m // 16) * 16, self.dims
         shape = {"jac": (k, 20 if rd == 7 else 13), "resid": (k,), "L": (kp, kp), "W": (kp, n), "A": (k, n),
-                 "stamps": (64,)}[what]
-        code = {"jac": 0, "resid": 1, "L": 2, "W": 3, "A": 4, "stamps": 5}[what]
+                 "stamps": (64,), "cov_stats": (32,)}[what]
+        code = {"jac": 0, "resid": 1, "L": 2, "W": 3, "A": 4, "stamps": 5, "cov_stats": 6}[what]
         out = np.empty(shape)
         self._check(self.lib.ekf_debug_fetch(self.h, code, _dptr(out), out.size))
         return out

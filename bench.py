@@ -47,7 +47,7 @@ def parse_args():
     ap.add_argument("--landmarks", type=int, default=1024)
     ap.add_argument("--visible", type=int, default=32)
     ap.add_argument("--cov-dtype", default="float32", choices=["float32", "float64"])
-    ap.add_argument("--cov-kernel", default="auto", choices=["auto", "valu", "mfma"])
+    ap.add_argument("--cov-kernel", default="auto", choices=["auto", "valu", "mfma", "mfma_tile", "mfma_macro"])
     ap.add_argument("--lookahead", choices=["auto", "on", "off"], default="auto",
                     help="pipelined sequence mode: front kernel of frame t+1 beside the covariance update of frame t (auto = by size)")
     ap.add_argument("--unfused", action="store_true",

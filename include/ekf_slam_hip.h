@@ -44,8 +44,11 @@ enum { EKF_QUAT_AS_WRITTEN = 0, EKF_QUAT_SCALAR_FIRST = 1 };
  * EKF_ROTATIONS = ekf_with_rotations.py (landmark [xyz | quat | err], 10 dims, 7 rows per
  * detection [xyz_cl ; q_cl], consistent quaternion convention, q_cam default 0.2) */
 enum { EKF_MODEL_EKF = 0, EKF_MODEL_ROTATIONS = 1 };
-/* covariance-update kernel selection (0 = best available) */
-enum { EKF_COVK_AUTO = 0, EKF_COVK_VALU = 1, EKF_COVK_MFMA = 2 };
+/* covariance-update kernel selection (0 = best available: as EKF_COVK_MFMA).  MFMA: the symmetric matrix-core kernels,
+ * one wave per 32 x 32 tile, and for the f32 covariance from 1024 tiles of 128 x 128 (n >= 1900 or so) one workgroup per
+ * 128 x 128 macro tile with LDS-staged operands; MFMA_TILE / MFMA_MACRO force one of the two (tests, measurements; MACRO:
+ * f32 only).  All of them give the same bits as the VALU reference kernel. */
+enum { EKF_COVK_AUTO = 0, EKF_COVK_VALU = 1, EKF_COVK_MFMA = 2, EKF_COVK_MFMA_TILE = 3, EKF_COVK_MFMA_MACRO = 4 };
 
 enum {
     EKF_OK = 0,

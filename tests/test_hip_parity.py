@@ -247,6 +247,46 @@ def test_mfma_and_valu_kernels_agree_bitwise(dtype):
     assert np.array_equal(res[0][1], res[1][1])
 
 
+@pytest.mark.parametrize("n,m", [(300, 5), (300, 16), (520, 37), (700, 64)])
+def test_macro_tile_cov_kernel_is_bitwise_the_other_kernels(n, m):
+    """f32, large problems: one workgroup per 128 x 128 macro tile, W staged through LDS by LDS-DMA, launch order from a
+    host-built table (csrc/ekf_cov_macro.hip; chosen from 1024 macro tiles on, forced here).  Same k-ascending fma chain
+    per element and v = (P + q) + acc as the wave-per-tile MFMA kernel and the VALU reference kernel: same bits.  The
+    shapes cover whole and half last chunks of W (k = 16, 48, 112, 192 rows) and several per-XCD list lengths."""
+    from aruco_slam_amd.synthetic import SyntheticStream
+    res = []
+    for kernel in ("valu", "mfma_tile", "mfma_macro"):
+        s = SyntheticStream(n, m, seed=7)
+        flt = _ekf(max_landmarks=n, max_visible=m, cov_dtype="float32", cov_kernel=kernel)
+        for ids, poses in list(s.bootstrap()) + list(s.steady(3)):
+            flt.observe(ids, poses)
+        res.append((flt.state, flt.uncertainty))
+    for other in res[1:]:
+        assert np.array_equal(res[0][0], other[0])
+        assert np.array_equal(res[0][1], other[1])
+    assert np.array_equal(res[2][1], res[2][1].T)
+
+
+def test_macro_tile_cov_kernel_in_the_pipelined_sequence_mode_is_bitwise_the_serial_order():
+    """The macro-tile kernel out of place (ping-pong covariance) beside the next frame's front kernel."""
+    import torch
+    from aruco_slam_amd.synthetic import SyntheticStream
+    n, m = 400, 24
+    out = []
+    for kernel, la in (("mfma_tile", False), ("mfma_macro", True)):
+        s = SyntheticStream(n, m, seed=11)
+        flt = _ekf(max_landmarks=n, max_visible=m, cov_dtype="float32", cov_kernel=kernel, lookahead=la)
+        for ids, poses in s.bootstrap():
+            flt.observe(ids, poses)
+        frames = list(s.steady(7))
+        idx = torch.tensor(np.stack([f[0] for f in frames]), dtype=torch.int32, device="cuda:0")
+        z = torch.tensor(np.stack([f[1][:, :3] for f in frames]), dtype=torch.float64, device="cuda:0")
+        flt.backend.observe_sequence(idx, z)
+        out.append((flt.state, flt.uncertainty))
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1])
+
+
 def test_full_size_properties_n1024_fp32():
     """BASELINE headline size: properties that need no oracle run."""
     from aruco_slam_amd.synthetic import SyntheticStream
