@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstdio>
@@ -16,6 +18,13 @@
 namespace {
 
 thread_local std::string g_err;
+
+// Pipelined sequence mode orders its two streams with device-side gates that spin.  HIP multiplexes streams onto a small
+// pool of hardware queues: with two handles pipelining at once, handle X's gate can sit in the queue in front of the
+// launch handle Y's gate waits for, and vice versa -- both poll budgets run out.  So at most ONE handle of the
+// process has gates in flight; another handle that asks for the pipelined mode meanwhile runs its call in serial order
+// (same results, bit for bit) and says so (ekf_last_sequence_mode).
+std::atomic<ekf_filter*> g_pipelining{nullptr};
 
 int fail(int code, const std::string& msg) {
     g_err = msg;
@@ -37,7 +46,7 @@ constexpr int kStageSlots = 64;   // pinned host ring for ekf_observe
 #define EKF_MACRO_SUPER 8
 #endif
 constexpr int kMacroSuper = EKF_MACRO_SUPER;    // macro-tile covariance update: super-tiles of 8 x 8 macro tiles per XCD (ekf_cov_macro.hip)
-constexpr int kMacroMinTiles = 1024;   // ... chosen from this many 128 x 128 tiles of the lower triangle (4 per CU)
+constexpr int kMacroMinTiles = 3000;   // ... chosen from this many 128 x 128 tiles of the lower triangle (n >= 3300 or so; measured: n=2048 1225 tiles 98 vs 80 us for the wave-per-tile kernel, n=4096 4753 tiles 290 vs 323)
 constexpr int kTimedKernels = 4;
 constexpr int kEventPool = 2048;  // frames of timing events kept before folding
 
@@ -172,6 +181,7 @@ struct ekf_filter {
     uint64_t done_total = 0;   // column chunks of fused frames enqueued since reset
     uint64_t la_base = 0;      // frames that went through the pipelined sequence mode since reset (device counters)
     int la_ok = -1;            // pipelined mode usable (-1: not probed yet; 0: the two streams share a hardware queue)
+    int seq_mode = EKF_SEQ_NONE;   // what the last ekf_observe_sequence_device call did (ekf_last_sequence_mode)
     // macro-tile covariance update: launch-order table in the workspace, rebuilt when the tile count changes
     int tiles_T = -1, tiles_grid = 0;
     uint32_t* tiles_host = nullptr;     // pinned staging copy
@@ -335,8 +345,7 @@ int enqueue_frame(ekf_filter* f, const int32_t* idx_dev, const double* z_dev, in
     if (use_front_kernel(f, fr)) {
         // one launch: timing slot 0 = the whole front kernel, slots 1 and 2 stay empty
         bind_exchange(f, fr);
-        static const bool no_mirror = getenv("EKF_NO_HOST_MIRROR") != nullptr;     // (experiments)
-        if (!f->timing && !no_mirror) {
+        if (!f->timing) {
             fr.state_host = reinterpret_cast<double*>(f->readback + 256);
             fr.status_host = reinterpret_cast<int32_t*>(f->readback + 128);
             f->mirror_fresh = true;
@@ -396,12 +405,13 @@ int sync_and_check(ekf_filter* f, int state_count = 0) {
         if (state_count > 0)
             HIP_TRY(hipMemcpyAsync(f->readback + 256, f->state, (size_t)state_count * 8, hipMemcpyDeviceToHost, f->stream));
         HIP_TRY(hipStreamSynchronize(f->stream));
+        ekf_filter* me = f;      // (everything this handle has enqueued is complete: its gates are gone)
+        (void)g_pipelining.compare_exchange_strong(me, nullptr);
     }
     const int32_t st = reinterpret_cast<const int32_t*>(f->readback)[0];
     f->status_clean = (st == 0);
     if (state_count == f->dims()) f->mirror_trust = true;      // (a full copy has just refreshed the mirror)
-    static const bool ignore = getenv("EKF_IGNORE_NUMERIC") != nullptr;   // timing ablations only
-    if (st != 0 && !ignore) {
+    if (st != 0) {
         // (sticky until ekf_reset: after any of these the filter state is not trustworthy)
         if (st & EKF_ST_BAD_INDEX)
             return fail(EKF_ERR_INVALID, "landmark index out of range in a device-resident detection array "
@@ -518,6 +528,10 @@ int ekf_destroy(ekf_filter* f) {
         (void)hipStreamSynchronize(f->big);
         (void)hipStreamDestroy(f->big);
     }
+    {
+        ekf_filter* me = f;
+        (void)g_pipelining.compare_exchange_strong(me, nullptr);
+    }
     for (int i = 0; i < 2; ++i) {
         if (f->ev_small[i]) (void)hipEventDestroy(f->ev_small[i]);
         if (f->ev_big[i]) (void)hipEventDestroy(f->ev_big[i]);
@@ -549,6 +563,90 @@ int ekf_bind_buffers(ekf_filter* f, void* cov_dev, int64_t ld, double* state_dev
     f->bound = true;
     f->is_reset = false;
     f->tiles_T = -1;
+    return EKF_OK;
+}
+
+int ekf_grow(ekf_filter* f, int32_t new_max_landmarks, int32_t new_max_visible, void* cov_dev, int64_t ld, double* state_dev,
+             void* workspace_dev, size_t workspace_bytes) {
+    if (!f) return fail(EKF_ERR_INVALID, "filter handle is NULL");
+    if (!f->bound || !f->is_reset) return fail(EKF_ERR_STATE, "ekf_grow needs a bound, reset filter");
+    if (new_max_landmarks < f->cfg.max_landmarks || new_max_visible < f->cfg.max_visible)
+        return fail(EKF_ERR_INVALID, "ekf_grow cannot shrink the capacity");
+    if (!cov_dev || !state_dev || !workspace_dev) return fail(EKF_ERR_INVALID, "NULL device buffer");
+    ekf_config ncfg = f->cfg;
+    ncfg.max_landmarks = new_max_landmarks;
+    ncfg.max_visible = new_max_visible;
+    {
+        int rc = check_config(&ncfg);
+        if (rc) return rc;
+    }
+    const Layout nl = make_layout(ncfg);
+    if (ld != nl.cap) return fail(EKF_ERR_INVALID, "ld must equal the value from ekf_query_sizes for the new capacity");
+    if (workspace_bytes < nl.total) return fail(EKF_ERR_INVALID, "workspace too small for the new capacity");
+    if ((reinterpret_cast<uintptr_t>(cov_dev) | reinterpret_cast<uintptr_t>(workspace_dev) |
+         reinterpret_cast<uintptr_t>(state_dev)) & 0xFF)
+        return fail(EKF_ERR_INVALID, "device buffers must be 256-byte aligned");
+    if (cov_dev == f->cov || state_dev == f->state || workspace_dev == static_cast<void*>(f->ws))
+        return fail(EKF_ERR_INVALID, "ekf_grow needs NEW buffers (the old ones are read)");
+    HIP_TRY(hipSetDevice(f->device));
+    HIP_TRY(hipStreamSynchronize(f->stream));
+    HIP_TRY(hipStreamSynchronize(f->big));
+    {
+        ekf_filter* me = f;
+        (void)g_pipelining.compare_exchange_strong(me, nullptr);
+    }
+    const Layout& ol = f->lay;
+    char* nws = static_cast<char*>(workspace_dev);
+    // pinned host buffers that are sized by the capacity
+    size_t nslot = align256((size_t)ncfg.max_visible * 4) + align256((size_t)ncfg.max_visible * 56);
+    if (nslot < align256(256 * 48) + align256(256 * 80)) nslot = align256(256 * 48) + align256(256 * 80);
+    if (nslot != f->slot_bytes) {       // (every slot's event is complete: the stream has just been synchronised)
+        char* npin = nullptr;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&npin), nslot * kStageSlots, hipHostMallocDefault));
+        (void)hipHostFree(f->pinned);
+        f->pinned = npin;
+        f->slot_bytes = nslot;
+    }
+    char* nread = nullptr;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&nread), 256 + (size_t)nl.cap * 8, hipHostMallocDefault));
+    uint32_t* ntiles = nullptr;
+    if (nl.tiles_cap > 0) {
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&ntiles), (size_t)nl.tiles_cap * 4, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            (void)hipHostFree(nread);
+            return fail(EKF_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+        }
+    }
+    // new buffers: zero (capacity padding stays exactly zero), exchange buffers armed, then the old contents
+    HIP_TRY(hipMemsetAsync(cov_dev, 0, (size_t)nl.cap * nl.cap * nl.elem, f->stream));
+    HIP_TRY(hipMemsetAsync(state_dev, 0, (size_t)nl.cap * 8, f->stream));
+    HIP_TRY(hipMemsetAsync(nws, 0, nl.total, f->stream));
+    HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(nws + nl.off_xl), (int)0xFFFBADC0u, nl.xl_len * 4, f->stream));
+    HIP_TRY(hipMemcpyAsync(state_dev, f->state, (size_t)ol.cap * 8, hipMemcpyDeviceToDevice, f->stream));
+    HIP_TRY(hipMemcpy2DAsync(cov_dev, (size_t)nl.cap * nl.elem, f->cov, (size_t)ol.cap * ol.elem, (size_t)ol.cap * ol.elem,
+                             (size_t)ol.cap, hipMemcpyDeviceToDevice, f->stream));
+    HIP_TRY(hipMemcpyAsync(nws + nl.off_status, f->ws + ol.off_status, 32, hipMemcpyDeviceToDevice, f->stream));   // (sticky bits stay)
+    HIP_TRY(hipStreamSynchronize(f->stream));
+    (void)hipHostFree(f->readback);
+    if (f->tiles_host) (void)hipHostFree(f->tiles_host);
+    f->readback = nread;
+    std::memset(f->readback, 0, 256 + (size_t)nl.cap * 8);
+    f->tiles_host = ntiles;
+    f->cfg = ncfg;
+    f->lay = nl;
+    f->cov = cov_dev;
+    f->ld = ld;
+    f->state = state_dev;
+    f->ws = nws;
+    // the workspace is new: everything that counts frames in it starts again (as after ekf_reset)
+    f->fseq = 0;
+    f->done_total = 0;
+    f->la_base = 0;
+    f->tiles_T = -1;
+    f->front_pending = false;
+    f->mirror_fresh = false;
+    f->mirror_trust = false;
+    f->status_clean = false;
     return EKF_OK;
 }
 
@@ -663,13 +761,7 @@ int ekf_observe(ekf_filter* f, const int32_t* lm_index, const double* z, int32_t
     // The kernels read the frame's detections (128 + 768 bytes at m = 32) straight from the pinned slot: a host-to-device
     // copy in front of them costs more (API call + DMA start, ~8 us before the front kernel begins) than the PCIe reads
     // cost the kernel's first round trip.  The slot is not reused before this frame's event (64-slot ring).
-    // EKF_COPY_DETECTIONS (experiments): the staged copy instead.
-    static const bool staged = getenv("EKF_COPY_DETECTIONS") != nullptr;
-    if (staged) {
-        HIP_TRY(hipMemcpyAsync(f->at<char>(L.off_idx), slot, (L.off_z - L.off_idx) + zb, hipMemcpyHostToDevice, f->stream));
-        rc = enqueue_frame(f, f->at<int32_t>(L.off_idx), f->at<double>(L.off_z), m, nullptr);
-    } else
-        rc = enqueue_frame(f, hidx, hz, m, nullptr);
+    rc = enqueue_frame(f, hidx, hz, m, nullptr);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(f->slot_done[f->slot], f->stream));
     f->slot = (f->slot + 1) % kStageSlots;
@@ -713,19 +805,48 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
         // The device-side gates need the two streams on DIFFERENT hardware queues (HIP maps streams to a small pool
         // of queues): a gate that shares its queue with the launch it waits for would wait for ever.  Probe once: a
         // gate on the internal stream, the matching signal on the handle's stream, a short poll budget.
+        // HIP deals its hardware queues to streams as they are created, so when the probe fails a FRESH internal stream usually
+        // sits on another queue: up to eight are tried before the handle settles for the serial order.
         unsigned long long* probe = f->at<unsigned long long>(f->lay.off_sync) + 2;
         int32_t* pstat = f->at<int32_t>(f->lay.off_sync) + 8;
-        HIP_TRY(hipMemsetAsync(probe, 0, 16, f->stream));
-        HIP_TRY(hipStreamSynchronize(f->stream));
-        ekf_launch_gate(probe, 1ull, pstat, f->big, 1 << 14);
-        ekf_launch_signal(probe, 1ull, f->stream);
-        HIP_TRY(hipStreamSynchronize(f->big));
-        HIP_TRY(hipStreamSynchronize(f->stream));
-        int32_t ps = 0;
-        HIP_TRY(hipMemcpy(&ps, pstat, 4, hipMemcpyDeviceToHost));
-        f->la_ok = (ps == 0) ? 1 : 0;
+        f->la_ok = 0;
+        for (int attempt = 0; attempt < 8 && f->la_ok == 0; ++attempt) {
+            if (attempt > 0) {
+                hipStream_t fresh = nullptr;
+                HIP_TRY(hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking));
+                HIP_TRY(hipStreamSynchronize(f->big));
+                (void)hipStreamDestroy(f->big);
+                f->big = fresh;
+            }
+            HIP_TRY(hipMemsetAsync(probe, 0, 64, f->stream));
+            HIP_TRY(hipStreamSynchronize(f->stream));
+            ekf_launch_gate(probe, 1ull, pstat, f->big, 1 << 14);
+            ekf_launch_signal(probe, 1ull, f->stream);
+            HIP_TRY(hipStreamSynchronize(f->big));
+            HIP_TRY(hipStreamSynchronize(f->stream));
+            int32_t ps = 0;
+            HIP_TRY(hipMemcpy(&ps, pstat, 4, hipMemcpyDeviceToHost));
+            f->la_ok = (ps == 0) ? 1 : 0;
+        }
     }
-    if (pipelined && f->la_ok == 0) pipelined = false;
+    f->seq_mode = EKF_SEQ_SERIAL;
+    if (pipelined && f->la_ok == 0) {
+        pipelined = false;
+        f->seq_mode = EKF_SEQ_SERIAL_ONE_QUEUE;
+    }
+    if (pipelined) {
+        // one pipelining handle per process (see g_pipelining): take the token, or take it over from a handle whose streams
+        // have drained, or run this call in serial order
+        ekf_filter* owner = nullptr;
+        if (!g_pipelining.compare_exchange_strong(owner, f) && owner != f) {
+            bool idle = hipStreamQuery(owner->stream) == hipSuccess && hipStreamQuery(owner->big) == hipSuccess;
+            (void)hipGetLastError();      // (hipErrorNotReady is not an error here)
+            if (!(idle && g_pipelining.compare_exchange_strong(owner, f))) {
+                pipelined = false;
+                f->seq_mode = EKF_SEQ_SERIAL_OTHER_HANDLE;
+            }
+        }
+    }
     if (!pipelined) {
         for (int t = 0; t < frames; ++t) {
             rc = enqueue_frame(f, lm_index_dev + (size_t)t * m, z_dev + (size_t)t * m * f->lay.rd, m,
@@ -764,10 +885,9 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
     unsigned long long* sync = f->at<unsigned long long>(L.off_sync);
     int32_t* status = f->at<int32_t>(L.off_status);
     const uint64_t base = f->la_base;
-    static const char* la_env = getenv("EKF_LA_LDS_KB");          // (experiments)
     const int nb_now = (int)round_up(L.rd * m, EKF_RB) / EKF_RB;
     const int grid_now = nb_now * (nb_now + 1) / 2 + 2 + (int)round_up(f->dims(), 128) / 64;
-    const int la_lds = la_env ? atoi(la_env) * 1024 : (grid_now <= 100 ? 148 * 1024 : 0);
+    const int la_lds = grid_now <= 100 ? 148 * 1024 : 0;
     // (stream B needs no edge from stream A at the start: its first launch is the gate in front of C(0), which waits
     // for "F(1) has started", i.e. for everything that is on stream A now and F(0); the previous call ended with
     // stream A waiting for stream B)
@@ -813,6 +933,7 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
         HIP_TRY(hipGetLastError());
     }
     f->la_base = base + (uint64_t)frames;
+    f->seq_mode = EKF_SEQ_PIPELINED;
     f->front_pending = false;
     f->status_clean = false;       // (gate kernels raise status bits without the host word)
     f->last_m = m;
@@ -964,6 +1085,8 @@ int ekf_set_cov(ekf_filter* f, const double* cov, int32_t dims) {
     }
     return EKF_OK;
 }
+
+int ekf_last_sequence_mode(const ekf_filter* f) { return f ? f->seq_mode : EKF_ERR_INVALID; }
 
 int ekf_set_fused(ekf_filter* f, int32_t enable) {
     if (!f) return fail(EKF_ERR_INVALID, "filter handle is NULL");

@@ -37,6 +37,23 @@ XYZ_DIMS = slice(0, 3)
 QUAT_DIMS = slice(3, 7)
 ERROR_DIMS = slice(7, 10)
 
+# markers in the predefined dictionaries, by OpenCV's enumeration (cv2.aruco.DICT_4X4_50 = 0 ... DICT_ARUCO_MIP_36h12 = 21):
+# how many landmarks a map built with that dictionary can hold (the filters size their first buffers for it; they grow
+# if more show up).  The reference's default is DICT_5X5_50 (base_filter.py:81-82).
+ARUCO_DICT_SIZES = {0: 50, 1: 100, 2: 250, 3: 1000, 4: 50, 5: 100, 6: 250, 7: 1000, 8: 50, 9: 100, 10: 250, 11: 1000,
+                    12: 50, 13: 100, 14: 250, 15: 1000, 16: 1024, 17: 30, 18: 35, 19: 2320, 20: 587, 21: 250}
+DEFAULT_ARUCO_DICT = 4      # cv2.aruco.DICT_5X5_50
+
+
+def dictionary_size(aruco_dict) -> int:
+    """Number of marker ids of the dictionary the filter was constructed with (None: the reference's default)."""
+    if aruco_dict is None:
+        aruco_dict = DEFAULT_ARUCO_DICT
+    try:
+        return ARUCO_DICT_SIZES[int(aruco_dict)]
+    except (KeyError, TypeError, ValueError):
+        return ARUCO_DICT_SIZES[DEFAULT_ARUCO_DICT]
+
 
 class BaseFilter:
     """Front-end + abstract back-end API (names and semantics of the reference)."""
@@ -124,21 +141,20 @@ class BaseFilter:
 
     def save_map(self, filename: str) -> None:
         """Map text format of base_filter.py:214-247: three comment lines and a
-        blank, then per landmark (index order) ``id``, ``x, y, z``,
-        ``ux, uy, uz`` and a blank line; numbers via ``str()``."""
-        _, marker_poses = self.get_poses()
-        index_to_id = {v: k for k, v in self.get_lm_estimates()}
-        uncertainties = self.get_lm_uncertainties()
-        with Path(filename).open("w", encoding="utf-8") as file:
-            file.write("# landmark_id\n")
-            file.write("# x y z\n")
-            file.write("# uncertainty\n")
-            file.write("\n")
-            for i, pose in enumerate(marker_poses):
-                file.write(f"{index_to_id[i]}\n")
-                file.write(f"{', '.join(map(str, pose))}\n")
-                file.write(f"{', '.join(map(str, uncertainties[i, :len(pose)]))}\n")
-                file.write("\n")
+        blank, then one record per landmark in index order -- marker id, pose
+        numbers, their variances (each ``", "``-separated through ``str()``) and a
+        blank line."""
+        _, rows = self.get_poses()
+        variances = self.get_lm_uncertainties()
+        marker_of = dict((index, marker) for marker, index in self.get_lm_estimates())
+
+        def record(index):
+            pose = rows[index]
+            numbers = (pose, variances[index, :len(pose)])
+            return "\n".join([str(marker_of[index])] + [", ".join(str(v) for v in vals) for vals in numbers]) + "\n\n"
+
+        header = "# landmark_id\n# x y z\n# uncertainty\n\n"
+        Path(filename).write_text(header + "".join(record(i) for i in range(len(rows))), encoding="utf-8")
 
     def load_map(self, filename: str) -> None:
         """Reader for the ``save_map`` format (base_filter.py:249-272: skip 4
@@ -152,6 +168,14 @@ class BaseFilter:
             pose = np.array(lines[i + 1].strip().split(", "), np.float64)
             uncertainty = np.array(lines[i + 2].strip().split(", "), np.float64)
             self.add_marker(id_, pose, uncertainty)
+
+    def reset(self) -> None:
+        """Back to the state of a freshly constructed filter (initial pose, no landmarks, status cleared): the way out
+        of a sticky device-side error (non-SPD innovation covariance, bad device-resident index, ...), usually followed
+        by ``load_checkpoint``."""
+        self.backend.reset(np.asarray(self._initial_pose, dtype=np.float64))
+        self.landmarks = {}
+        self.num_landmarks = 0
 
     # -- resume (SURVEY 8 f4; no reference counterpart: its map restore is the dead :249-272) -----
     def save_checkpoint(self, filename: str) -> None:

@@ -14,7 +14,7 @@ from __future__ import annotations
 import numpy as np
 
 from ..hip_backend import HipEkf
-from .base_filter import BaseFilter
+from .base_filter import BaseFilter, dictionary_size
 
 INITIAL_CAMERA_UNCERTAINTY = 0.1
 INITIAL_LANDMARK_UNCERTAINTY = 0.7
@@ -43,7 +43,7 @@ def euler_xyz_to_quat(angles) -> np.ndarray:
 class EKF_Rotations(BaseFilter):  # noqa: N801  (name of the reference class)
     """Object for tracking the poses of the camera and of the landmarks."""
 
-    def __init__(self, initial_camera_pose, *, max_landmarks: int = 50, max_visible: int | None = None,
+    def __init__(self, initial_camera_pose, *, max_landmarks: int | None = None, max_visible: int | None = None,
                  cov_dtype: str = "float64", cov_kernel: str = "auto", device: str = "cuda:0",
                  lookahead: bool | None = None, fused: bool = True) -> None:
         super().__init__(initial_camera_pose, None)
@@ -52,6 +52,8 @@ class EKF_Rotations(BaseFilter):  # noqa: N801  (name of the reference class)
             raise ValueError("initial_camera_pose must have 10 entries")
         self.num_landmarks = 0
         self.landmarks = {}
+        if max_landmarks is None:
+            max_landmarks = dictionary_size(None)    # (the reference's EKF_Rotations takes no aruco_dict: DICT_5X5_50)
         if max_visible is None:
             max_visible = min(max_landmarks, 27)     # 7 rows per detection, k <= 192
         self._hip = HipEkf(max_landmarks, max_visible, cov_dtype=cov_dtype, quat_mode="scalar_first",

@@ -11,7 +11,7 @@ from __future__ import annotations
 import numpy as np
 
 from ..hip_backend import HipEkf
-from .base_filter import BaseFilter
+from .base_filter import BaseFilter, dictionary_size
 
 MOVING_AVG_WINDOW = 10   # unused in the reference as well (:19)
 
@@ -32,13 +32,15 @@ LM_DIMS = 3
 class EKF(BaseFilter):
     """Object for tracking the positions of the camera and landmarks."""
 
-    def __init__(self, initial_camera_pose, aruco_dict=None, *, max_landmarks: int = 50,
+    def __init__(self, initial_camera_pose, aruco_dict=None, *, max_landmarks: int | None = None,
                  max_visible: int | None = None, cov_dtype: str = "float64",
                  quat_update: str = "as_written", cov_kernel: str = "auto",
                  device: str = "cuda:0", map_file=None, lookahead: bool | None = None,
                  fused: bool = True) -> None:
         """Positional arguments as the reference (:40-43).  Keyword-only extras:
-        capacity (DICT_5X5_50 has 50 ids, base_filter.py:81-82), covariance
+        initial capacity (default: the number of ids of ``aruco_dict`` -- DICT_5X5_50
+        has 50, base_filter.py:81-82; the buffers grow when more markers or more
+        detections per frame show up, as the reference's arrays do, :274-290), covariance
         storage dtype, and the quaternion-injection convention
         (``"as_written"`` reproduces :138-149 exactly, ``"scalar_first"`` is the
         consistent one)."""
@@ -48,6 +50,8 @@ class EKF(BaseFilter):
             raise ValueError("initial_camera_pose must have 10 entries")
         self.num_landmarks = 0
         self.landmarks = {}
+        if max_landmarks is None:
+            max_landmarks = dictionary_size(aruco_dict)
         if max_visible is None:
             max_visible = min(max_landmarks, 64)
         self._hip = HipEkf(max_landmarks, max_visible, cov_dtype=cov_dtype,

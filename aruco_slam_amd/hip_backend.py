@@ -22,8 +22,8 @@ EKF_COVK_AUTO, EKF_COVK_VALU, EKF_COVK_MFMA, EKF_COVK_MFMA_TILE, EKF_COVK_MFMA_M
 # every symbol include/ekf_slam_hip.h declares
 EXPORTED_SYMBOLS = (
     "ekf_default_config", "ekf_query_sizes", "ekf_create", "ekf_destroy", "ekf_bind_buffers",
-    "ekf_reset", "ekf_add_markers", "ekf_observe", "ekf_observe_device",
-    "ekf_observe_sequence_device", "ekf_get_camera", "ekf_get_state", "ekf_get_cov_diag",
+    "ekf_reset", "ekf_grow", "ekf_add_markers", "ekf_observe", "ekf_observe_device",
+    "ekf_observe_sequence_device", "ekf_last_sequence_mode", "ekf_get_camera", "ekf_get_state", "ekf_get_cov_diag",
     "ekf_get_cov", "ekf_set_state", "ekf_set_cov", "ekf_num_landmarks", "ekf_sync",
     "ekf_set_fused", "ekf_set_kernel_timing", "ekf_get_kernel_timing", "ekf_debug_fetch",
     "ekf_estimate_poses_device", "ekf_estimate_poses", "ekf_last_error_string",
@@ -73,6 +73,7 @@ def load_library(path: str | Path | None = None):
         "ekf_destroy": [vp],
         "ekf_bind_buffers": [vp, vp, C.c_int64, vp, vp, C.c_size_t],
         "ekf_reset": [vp, dp],
+        "ekf_grow": [vp, C.c_int32, C.c_int32, vp, C.c_int64, vp, vp, C.c_size_t],
         "ekf_add_markers": [vp, dp, dp, C.c_int32],
         "ekf_observe": [vp, ip, dp, C.c_int32],
         "ekf_observe_device": [vp, vp, vp, C.c_int32],
@@ -84,6 +85,7 @@ def load_library(path: str | Path | None = None):
         "ekf_set_state": [vp, dp, C.c_int32],
         "ekf_set_cov": [vp, dp, C.c_int32],
         "ekf_num_landmarks": [vp],
+        "ekf_last_sequence_mode": [vp],
         "ekf_sync": [vp],
         "ekf_set_fused": [vp, C.c_int32],
         "ekf_set_kernel_timing": [vp, C.c_int32],
@@ -131,6 +133,7 @@ class HipEkf:
     """One filter instance = one C handle + the torch tensors it borrows."""
 
     KERNEL_NAMES = ("gather", "solve", "panel", "cov_update")
+    MAX_VISIBLE_LIMIT = {3: 64, 10: 27}      # detections per frame the kernels take (by landmark width: EKF / EKF_Rotations)
 
     def __init__(self, max_landmarks: int, max_visible: int, cov_dtype="float64",
                  quat_mode="as_written", cov_kernel="auto", device="cuda:0", noise=None,
@@ -211,8 +214,34 @@ class HipEkf:
         assert p.shape == (10,)
         self._check(self.lib.ekf_reset(self.h, _dptr(p)))
 
+    def grow(self, new_max_landmarks: int | None = None, new_max_visible: int | None = None):
+        """Move the filter into buffers for a larger capacity (ekf_grow): new tensors sized by ekf_query_sizes, the library
+        copies state / covariance device to device and re-binds; the old tensors are released afterwards."""
+        torch = self._torch
+        cfg = self.cfg
+        new_max_landmarks = self.max_landmarks if new_max_landmarks is None else int(new_max_landmarks)
+        new_max_visible = self.max_visible if new_max_visible is None else int(new_max_visible)
+        ncfg = EkfConfig()
+        C.memmove(C.byref(ncfg), C.byref(cfg), C.sizeof(EkfConfig))
+        ncfg.max_landmarks = int(new_max_landmarks)
+        ncfg.max_visible = int(new_max_visible)
+        with torch.cuda.device(self.device):
+            ld, cb, sb, wb = C.c_int64(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+            self._check(self.lib.ekf_query_sizes(C.byref(ncfg), C.byref(ld), C.byref(cb), C.byref(sb), C.byref(wb)))
+            cov_t = torch.empty((ld.value, ld.value), dtype=self.cov_t.dtype, device=self.device)
+            state_t = torch.empty((sb.value // 8,), dtype=torch.float64, device=self.device)
+            ws_t = torch.empty((wb.value,), dtype=torch.uint8, device=self.device)
+            torch.cuda.synchronize(self.device)
+            self._check(self.lib.ekf_grow(self.h, int(new_max_landmarks), int(new_max_visible), cov_t.data_ptr(), ld.value,
+                                          state_t.data_ptr(), ws_t.data_ptr(), wb.value))
+        self.cov_t, self.state_t, self.ws_t, self.ld = cov_t, state_t, ws_t, ld.value
+        self.cfg = ncfg
+        self.max_landmarks, self.max_visible = int(new_max_landmarks), int(new_max_visible)
+
     def add_markers(self, xyz, uncertainty=None):
         xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 6 if self.lm_dims == 10 else 3)
+        if self.num_landmarks + xyz.shape[0] > self.max_landmarks:      # the reference appends without limit (:274-290)
+            self.grow(max(2 * self.max_landmarks, self.num_landmarks + xyz.shape[0]))
         unc = None
         if uncertainty is not None:
             unc = np.ascontiguousarray(
@@ -225,6 +254,8 @@ class HipEkf:
         z = np.ascontiguousarray(z, dtype=np.float64).reshape(-1, self.rows_per_detection)
         assert idx.shape[0] == z.shape[0]
         self._last_m = idx.shape[0]
+        if idx.shape[0] > self.max_visible:      # the reference takes any number of detections per frame (:158-200)
+            self.grow(new_max_visible=min(self.MAX_VISIBLE_LIMIT[self.lm_dims], max(2 * self.max_visible, idx.shape[0])))
         self._check(self.lib.ekf_observe(self.h, idx.ctypes.data_as(C.POINTER(C.c_int32)), _dptr(z),
                                          idx.shape[0]))
 
@@ -238,6 +269,13 @@ class HipEkf:
         self._check(self.lib.ekf_observe_sequence_device(
             self.h, idx_t.data_ptr(), z_t.data_ptr(), m, frames,
             traj_t.data_ptr() if traj_t is not None else None))
+
+    SEQUENCE_MODES = {0: "none", 1: "serial", 2: "pipelined", 3: "serial (the two streams share one hardware queue)",
+                      4: "serial (another handle of the process is pipelining)"}
+
+    def last_sequence_mode(self) -> str:
+        """What the last observe_sequence call did (ekf_last_sequence_mode)."""
+        return self.SEQUENCE_MODES[self.lib.ekf_last_sequence_mode(self.h)]
 
     def sync(self):
         self._check(self.lib.ekf_sync(self.h))
@@ -262,6 +300,8 @@ class HipEkf:
     def set_state_cov(self, state, cov):
         state = np.ascontiguousarray(state, dtype=np.float64)
         n_lm = (state.shape[0] - 10) // self.lm_dims
+        if n_lm > self.max_landmarks:
+            self.grow(n_lm)
         self._check(self.lib.ekf_set_state(self.h, _dptr(state), n_lm))
         cov = np.ascontiguousarray(cov, dtype=np.float64)
         assert cov.shape == (state.shape[0], state.shape[0])

@@ -45,7 +45,7 @@ enum { EKF_QUAT_AS_WRITTEN = 0, EKF_QUAT_SCALAR_FIRST = 1 };
  * detection [xyz_cl ; q_cl], consistent quaternion convention, q_cam default 0.2) */
 enum { EKF_MODEL_EKF = 0, EKF_MODEL_ROTATIONS = 1 };
 /* covariance-update kernel selection (0 = best available: as EKF_COVK_MFMA).  MFMA: the symmetric matrix-core kernels,
- * one wave per 32 x 32 tile, and for the f32 covariance from 1024 tiles of 128 x 128 (n >= 1900 or so) one workgroup per
+ * one wave per 32 x 32 tile, and for the f32 covariance from 3000 tiles of 128 x 128 (n >= 3300 or so) one workgroup per
  * 128 x 128 macro tile with LDS-staged operands; MFMA_TILE / MFMA_MACRO force one of the two (tests, measurements; MACRO:
  * f32 only).  All of them give the same bits as the VALU reference kernel. */
 enum { EKF_COVK_AUTO = 0, EKF_COVK_VALU = 1, EKF_COVK_MFMA = 2, EKF_COVK_MFMA_TILE = 3, EKF_COVK_MFMA_MACRO = 4 };
@@ -72,7 +72,9 @@ typedef struct ekf_config {
                              * beside the covariance update of frame t; same results, bit for bit): 0 = chosen by size
                              * (MFMA covariance update only, either dtype; on from 200 state dimensions, except
                              * above 9000 with more than 32 detections per frame), bit 0 = never, bit 1 = always.  Unless bit 0
-                             * is set, a capable configuration adds a second covariance buffer to the workspace.
+                             * is set, a capable configuration adds a second covariance buffer to the workspace
+                             * (ekf_query_sizes: + ld^2 elements).  One handle per process pipelines at a time
+                             * (ekf_last_sequence_mode).
                              * bit 2: run gather / solve / panel as three separate launches instead of the fused front
                              * kernel (same results, bit for bit; no pipelined mode).  bit 3 is ignored. */
     /* noise constants, defaults = extended_kalman_filter.py:21-27 */
@@ -99,6 +101,15 @@ int ekf_destroy(ekf_filter *f);
 /* Borrow caller-owned device memory (see ekf_query_sizes). */
 int ekf_bind_buffers(ekf_filter *f, void *cov_dev, int64_t ld, double *state_dev,
                      void *workspace_dev, size_t workspace_bytes);
+
+/* Capacity growth.  The reference appends landmarks without limit (extended_kalman_filter.py:274-290: hstack / block
+ * matrix per add_marker); here the capacity is fixed by the buffers, and a filter that is about to exceed max_landmarks
+ * moves into larger ones (likewise for more detections per frame than max_visible): the caller sizes new buffers with
+ * ekf_query_sizes for the same configuration with the new max_landmarks / max_visible (neither may shrink), and the library copies state, covariance (device to device, capacity padding zero) and
+ * the status word, re-arms its workspace and borrows the new buffers from then on; the old ones may be freed when the call
+ * returns.  The filter continues bit for bit as one that had been created with the larger capacity. */
+int ekf_grow(ekf_filter *f, int32_t new_max_landmarks, int32_t new_max_visible, void *cov_dev, int64_t ld,
+             double *state_dev, void *workspace_dev, size_t workspace_bytes);
 
 /* state = initial pose, P = 0.1 I_10, no landmarks
  * (extended_kalman_filter.py:46-51). */
@@ -144,6 +155,13 @@ int ekf_observe_device(ekf_filter *f, const int32_t *lm_index_dev,
 int ekf_observe_sequence_device(ekf_filter *f, const int32_t *lm_index_dev,
                                 const double *z_dev, int32_t m, int32_t frames,
                                 double *trajectory_dev);
+/* What the last ekf_observe_sequence_device call of this handle did (results are the same bits in every mode):
+ * PIPELINED; SERIAL (not asked for / not chosen for this size, fewer than 2 frames, kernel timing on, stage kernels);
+ * SERIAL_ONE_QUEUE: asked for, but the handle's two streams share one hardware queue (found by a self-test on first use);
+ * SERIAL_OTHER_HANDLE: asked for, but another handle of the process has a pipelined call in flight -- the device-side
+ * gates of two handles could wait for each other across the shared hardware queues, so only one handle pipelines at a time. */
+enum { EKF_SEQ_NONE = 0, EKF_SEQ_SERIAL = 1, EKF_SEQ_PIPELINED = 2, EKF_SEQ_SERIAL_ONE_QUEUE = 3, EKF_SEQ_SERIAL_OTHER_HANDLE = 4 };
+int ekf_last_sequence_mode(const ekf_filter *f);
 
 /* EKF.get_poses / get_lm_uncertainties (extended_kalman_filter.py:84-93).
  * Synchronise and copy to host.  ekf_get_camera / ekf_get_state directly after ekf_observe / ekf_observe_device wait

@@ -347,6 +347,9 @@ def test_resident_sequence_entry_matches_per_frame_calls(dtype, kernel):
             traj = torch.zeros((len(frames), 7), dtype=torch.float64, device="cuda")
             flt.backend.observe_sequence(idx[:5], z[:5], traj[:5])     # two calls back to back:
             flt.backend.observe_sequence(idx[5:], z[5:], traj[5:])     # the join must hold
+            # (the test must not pass vacuously: the VALU kernel has no pipelined mode, the others must have used it)
+            want = "pipelined" if (mode == "sequence" and kernel != "valu") else "serial"
+            assert flt.backend.last_sequence_mode() == want
             flt.backend.sync()
             tr = traj.cpu().numpy()
         outs.append((tr, flt.state, flt.uncertainty))
@@ -408,6 +411,7 @@ def test_pipelined_sequence_mode_at_headline_size_is_bitwise_the_serial_order():
         traj = torch.zeros((len(frames), 7), dtype=torch.float64, device="cuda")
         for lo, hi in ((0, 30), (30, 31), (31, 70)):
             flt.backend.observe_sequence(idx[lo:hi], z[lo:hi], traj[lo:hi])
+        assert flt.backend.last_sequence_mode() == ("serial" if mode is False else "pipelined")
         flt.backend.sync()
         outs.append((traj.cpu().numpy(), flt.state, flt.uncertainty))
         del flt
@@ -418,22 +422,29 @@ def test_pipelined_sequence_mode_at_headline_size_is_bitwise_the_serial_order():
 
 
 def test_error_behaviour():
+    """Errors at the boundary: Python exceptions, as in the reference; the C ABI's capacity errors are still there for a caller
+    that does not grow (the Python classes do: test_filter_that_outgrows_its_buffers_equals_one_built_large)."""
+    import ctypes as C
     from aruco_slam_amd.hip_backend import EkfError
     flt = _ekf(max_landmarks=4, max_visible=2)
     with pytest.raises(ValueError):
         flt.observe([], np.zeros((0, 6)))
     poses = np.tile(np.array([0.1, 0.2, 5.0, 0, 0, 0]), (3, 1))
+    hip = flt.backend
+    flt.observe([1, 2], poses[:2])
+    idx = np.array([0, 1, 1], dtype=np.int32)
+    z = np.ascontiguousarray(poses[:, :3])
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    rc = hip.lib.ekf_observe(hip.h, idx.ctypes.data_as(ip), z.ctypes.data_as(dp), 3)      # 3 detections > max_visible
+    assert rc == -2 and b"max_visible" in hip.lib.ekf_last_error_string()
+    xyz = np.ascontiguousarray(np.tile(poses[:1, :3], (3, 1)))
+    rc = hip.lib.ekf_add_markers(hip.h, xyz.ctypes.data_as(dp), None, 3)                    # 2 + 3 landmarks > max_landmarks
+    assert rc == -2 and b"max_landmarks" in hip.lib.ekf_last_error_string()
     with pytest.raises(EkfError) as e:
-        flt.observe([1, 2, 3], poses)            # 3 detections > max_visible
-    assert e.value.code == -2
-    flt2 = _ekf(max_landmarks=2, max_visible=2)
-    flt2.observe([1, 2], poses[:2])
-    with pytest.raises(EkfError) as e:
-        flt2.observe([3], poses[:1])             # third landmark > capacity
-    assert e.value.code == -2
-    with pytest.raises(EkfError) as e:
-        flt2.backend.observe([5], poses[:1, :3])  # index out of range
+        hip.observe([5], poses[:1, :3])          # index out of range
     assert e.value.code == -1
+    flt.observe([1, 2, 3], poses)                # through the class: the filter grows instead
+    assert flt.num_landmarks == 3 and hip.max_visible >= 3
 
 
 def test_add_marker_with_uncertainty_and_duplicates():
@@ -793,8 +804,11 @@ def test_c5_size_back_to_back_frames_fused_vs_separate_launches():
         assert np.array_equal(outs[0][1], other[1])
 
 
-def test_c5_full_size_properties_and_oracle_steps():
-    """BASELINE configs[4] (n=4096, m=64, N=12298, k=192, f32 covariance) through the fused front kernel:
+@pytest.mark.parametrize("quat", ["scalar_first", "as_written"])
+def test_c5_full_size_properties_and_oracle_steps(quat):
+    """(Both quaternion conventions: `as_written` is the reference's own, extended_kalman_filter.py:138-149; teacher-forced
+    steps from a common (state, P) do not amplify its chaos.)
+    BASELINE configs[4] (n=4096, m=64, N=12298, k=192, f32 covariance) through the fused front kernel:
     (i) properties of one update at full size -- downdate identity P' + W^T W = P + Q with the debug copy
     of W, bitwise symmetry, zero capacity padding, variances positive and not growing beyond P + Q;
     (ii) three steady frames against the CPU oracle (fast mode) started from the SAME (state, P): the
@@ -806,7 +820,7 @@ def test_c5_full_size_properties_and_oracle_steps():
     n, m = 4096, 64
     dims = 3 * n + 10
     s = SyntheticStream(n, m, seed=5)
-    flt = _ekf(max_landmarks=n, max_visible=m, cov_dtype="float32", quat_update="scalar_first")
+    flt = _ekf(max_landmarks=n, max_visible=m, cov_dtype="float32", quat_update=quat)
     assert flt.backend.fused is True
     flt.backend.debug_enable_w()
     for ids, poses in s.bootstrap():
@@ -816,7 +830,7 @@ def test_c5_full_size_properties_and_oracle_steps():
         flt.observe(ids, poses)
     state0, p0 = flt.state, flt.uncertainty
     # ---- (ii) oracle from the same prior
-    orc = _oracle(mode="fast", quat_mode="scalar_first")
+    orc = _oracle(mode="fast", quat_mode=quat)
     _restore_oracle(orc, state0, p0, list(range(n)))
     q = np.full(dims, 0.01)
     q[0:3], q[3:7], q[7:10] = 0.3, 0.0, 0.5
@@ -844,10 +858,12 @@ def test_c5_full_size_properties_and_oracle_steps():
             full = rel_err(p1, orc.uncertainty)
             assert full <= 5e-6, full
             del p1
-    report("c5_oracle_steps[float32]", state_norm=worst[0], diag_norm=worst[1], state_elem=worst[2], diag_elem=worst[3],
+    report(f"c5_oracle_steps[float32,{quat}]", state_norm=worst[0], diag_norm=worst[1], state_elem=worst[2], diag_elem=worst[3],
            downdate_identity=ident, cov_norm_step1=full)
-    assert worst[0] <= 5e-6 and worst[1] <= 5e-6, worst          # measured 3e-9 / 6e-7
-    assert worst[2] <= 5e-5 and worst[3] <= 5e-5, worst          # measured 2e-7 / 6e-6
+    assert worst[0] <= 5e-6 and worst[1] <= 5e-6, worst          # measured 3e-9 / 6e-7 (as_written: 4e-9 / 4e-7)
+    # element-wise (floor 1e-3): scalar_first measured 2e-7 / 6e-6; as_written 5e-7 / 1.9e-4 (the as-written filter has
+    # drifted by then -- SURVEY F5 -- and its small variances are a few f32 ulps of the large ones they are differences of)
+    assert worst[2] <= 5e-5 and worst[3] <= (5e-5 if quat == "scalar_first" else 8e-4), worst
 
 
 @pytest.mark.parametrize("make,n,m,dtype", [(_ekf, 300, 20, "float32"), (_ekf, 128, 64, "float64"), (_rot, 40, 12, "float32")])
@@ -1004,3 +1020,125 @@ def test_pose_front_end_kernel_vs_oracle_and_projected_poses():
     with pytest.raises(hip_backend.EkfError) as e:
         hip_backend.estimate_poses(corners[:2], 0.16, k, np.zeros(9))          # 9 distortion coefficients
     assert e.value.code == -1
+
+
+# ---------------------------------------------------------------------------
+# capacity that follows the reference (extended_kalman_filter.py:274-290: arrays grow without limit)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("make,dtype", [("_ekf", "float64"), ("_ekf", "float32"), ("_rot", "float32")])
+def test_filter_that_outgrows_its_buffers_equals_one_built_large(make, dtype):
+    """A filter constructed for 8 landmarks / 4 detections per frame that meets 20 markers and frames of up to 9 detections
+    moves into larger buffers (ekf_grow: new tensors from ekf_query_sizes, device-to-device copy, re-bind) instead of
+    failing with EKF_ERR_CAPACITY -- and continues BIT FOR BIT like a filter that was built for 32 / 16 from the start."""
+    from aruco_slam_amd.synthetic import SyntheticStream
+    maker = {"_ekf": _ekf, "_rot": _rot}[make]
+    outs = []
+    for cap, vis in ((8, 4), (32, 16)):
+        rng = np.random.default_rng(4)
+        s = SyntheticStream(20, 4, seed=12, rvec_sigma=0.05 if make == "_rot" else 0.0)
+        flt = maker(max_landmarks=cap, max_visible=vis, cov_dtype=dtype)
+        seen = []
+        for t in range(26):
+            m = int(rng.integers(2, 10))
+            known = min(20, 3 + t)                       # markers appear progressively: several growth steps
+            ids = np.sort(rng.choice(known, min(m, known), replace=False))
+            if t >= 20:
+                ids = np.unique(np.concatenate([ids[:-1], [16 + (t - 20) % 4]]))      # (every marker is seen at least once)
+            ids_f, poses = s._observe(ids)
+            flt.observe(ids_f, poses)
+            seen.append(flt.state[:7].copy())
+        assert flt.num_landmarks == 20
+        assert flt.backend.max_landmarks >= 20 and flt.backend.max_visible >= 9
+        outs.append((np.stack(seen), flt.state, flt.uncertainty, flt.get_lm_uncertainties()))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
+def test_default_capacity_follows_the_dictionary():
+    """EKF(initial_pose, aruco_dict) as the reference constructs it (extended_kalman_filter.py:40-43): the first buffers are
+    sized for the dictionary's marker count (DICT_5X5_50 by default, base_filter.py:81-82)."""
+    assert _ekf().backend.max_landmarks == 50
+    from aruco_slam_amd.filters.extended_kalman_filter import EKF
+    assert EKF(INIT, 6).backend.max_landmarks == 250          # cv2.aruco.DICT_5X5_250
+    assert _rot().backend.max_landmarks == 50
+
+
+@pytest.mark.parametrize("make", ["_ekf", "_rot"])
+def test_sticky_device_error_recovers_through_reset_and_load_checkpoint(tmp_path, make):
+    """A device-side error (here: a landmark index out of range in a device-resident detection array, raised by the kernels)
+    is sticky: every synchronising call reports it until ekf_reset.  The way back is reset() + load_checkpoint(): the
+    restored filter continues bit for bit like one that never failed."""
+    import torch
+    from aruco_slam_amd.hip_backend import EkfError
+    from aruco_slam_amd.synthetic import SyntheticStream
+    maker = {"_ekf": _ekf, "_rot": _rot}[make]
+    rot = make == "_rot"
+    s = SyntheticStream(24, 6, seed=8, rvec_sigma=0.05 if rot else 0.0)
+    frames = list(s.bootstrap()) + list(s.steady(8))
+    good = maker(max_landmarks=24, max_visible=6, cov_dtype="float64")
+    bad = maker(max_landmarks=24, max_visible=6, cov_dtype="float64")
+    for ids, poses in frames[:6]:
+        good.observe(ids, poses)
+        bad.observe(ids, poses)
+    ck = tmp_path / "ck.npz"
+    bad.save_checkpoint(str(ck))
+    # poison: one resident frame with an index beyond the map
+    rd = 7 if rot else 3
+    idx = torch.tensor([[0, 1, 2, 3, 4, 99]], dtype=torch.int32, device="cuda")
+    z = torch.zeros((1, 6, rd), dtype=torch.float64, device="cuda")
+    if rot:
+        z[:, :, 3] = 1.0
+    bad.backend.observe_sequence(idx, z)
+    with pytest.raises(EkfError) as err:
+        bad.backend.sync()
+    assert err.value.code == -1                      # EKF_ERR_INVALID, reported by the kernels
+    with pytest.raises(EkfError):                    # ... and sticky
+        bad.backend.get_state()
+    bad.reset()
+    assert bad.num_landmarks == 0
+    bad.load_checkpoint(str(ck))
+    for ids, poses in frames[6:]:
+        good.observe(ids, poses)
+        bad.observe(ids, poses)
+    assert np.array_equal(good.state, bad.state)
+    assert np.array_equal(good.uncertainty, bad.uncertainty)
+
+
+def test_only_one_handle_of_a_process_pipelines_at_a_time():
+    """Two filters with pipelined sequence calls in flight: the device-side gates of two handles could wait for each other
+    across the hardware queues HIP multiplexes its streams onto, so the second handle runs its call in serial
+    order -- same bits -- and says so; once the first handle has been synchronised the second one may pipeline."""
+    import torch
+    from aruco_slam_amd.synthetic import SyntheticStream
+    n, m = 300, 16
+    filters, data = [], []
+    for seed in (1, 2):
+        s = SyntheticStream(n, m, seed=seed)
+        flt = _ekf(max_landmarks=n, max_visible=m, cov_dtype="float32", lookahead=True)
+        for ids, poses in s.bootstrap():
+            flt.observe(ids, poses)
+        fr = list(s.steady(400))
+        idx = torch.tensor(np.stack([f[0] for f in fr]), dtype=torch.int32, device="cuda")
+        z = torch.tensor(np.stack([f[1][:, :3] for f in fr]), dtype=torch.float64, device="cuda")
+        flt.backend.sync()
+        filters.append(flt)
+        data.append((idx, z, fr))
+    a, b = filters
+    a.backend.observe_sequence(data[0][0], data[0][1])           # 400 frames in flight ...
+    b.backend.observe_sequence(data[1][0], data[1][1])           # ... when the second handle asks
+    assert a.backend.last_sequence_mode() == "pipelined"
+    assert b.backend.last_sequence_mode() in ("serial (another handle of the process is pipelining)", "pipelined")
+    a.backend.sync()
+    b.backend.sync()
+    b.backend.observe_sequence(data[1][0][:4], data[1][1][:4])
+    assert b.backend.last_sequence_mode() == "pipelined"
+    b.backend.sync()
+    # same bits as a run that never pipelined
+    ref = _ekf(max_landmarks=n, max_visible=m, cov_dtype="float32", lookahead=False)
+    s = SyntheticStream(n, m, seed=2)
+    for ids, poses in s.bootstrap():
+        ref.observe(ids, poses)
+    ref.backend.observe_sequence(data[1][0], data[1][1])
+    ref.backend.observe_sequence(data[1][0][:4], data[1][1][:4])
+    assert np.array_equal(ref.state, b.state)
+    assert np.array_equal(ref.uncertainty, b.uncertainty)

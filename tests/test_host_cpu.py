@@ -212,6 +212,45 @@ def test_euler_xyz_to_quat_matches_pinned_oracle():
     assert np.abs(np.linalg.norm(got, axis=1) - 1.0).max() <= 1e-15
 
 
+def test_bench_launches_its_own_ranks(monkeypatch, capsys):
+    """`python bench.py --gpus N` as the driver calls it (no outer launcher, no WORLD_SIZE): the parent becomes the launcher --
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same arguments>` as a
+    child process -- relays rank 0's JSON line and returns the child's exit code, before anything touches the GPU."""
+    import importlib.util
+    import subprocess
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_under_test", REPO / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cmd = bench.launcher_command(4, ["--gpus", "4", "--steps", "20", "--warmup", "5"], 29517)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29517"
+    assert cmd[-7:] == [str(REPO / "bench.py"), "--gpus", "4", "--steps", "20", "--warmup", "5"]
+    seen = {}
+
+    def fake_run(argv, env=None, stdout=None, text=None):
+        seen["argv"], seen["env"] = argv, env
+        return subprocess.CompletedProcess(argv, 3, stdout='noise\n{"metric": "EKF updates/sec", "value": 1.0, "n_gpus": 2}\n')
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "7"])
+    with pytest.raises(SystemExit) as stop:
+        bench.main()
+    assert stop.value.code == 3                                     # the child's exit code
+    assert seen["argv"][-4:] == ["--gpus", "2", "--steps", "7"] and "--nproc-per-node=2" in seen["argv"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert capsys.readouterr().out.strip() == '{"metric": "EKF updates/sec", "value": 1.0, "n_gpus": 2}'
+    assert bench.parse_args(["--filter", "ekf_rotations"]).landmarks == 400
+
+
+def test_dictionary_sizes_and_default():
+    from aruco_slam_amd.filters.base_filter import dictionary_size
+    assert dictionary_size(None) == 50 and dictionary_size(4) == 50        # DICT_5X5_50, base_filter.py:81-82
+    assert dictionary_size(7) == 1000 and dictionary_size(16) == 1024 and dictionary_size("x") == 50
+
+
 def test_hand_counted_kernels_do_not_spill(tmp_path):
     """ekf_cov_update_mfma_f32 issues its loads as inline asm and counts them for s_waitcnt by hand: a
     register spill (scratch traffic on the same counter) would silently break the counting."""
@@ -228,6 +267,13 @@ def test_hand_counted_kernels_do_not_spill(tmp_path):
     assert all(int(spills) == 0 for _, spills in kernels), kernels
     scratch = re.findall(r"\.name:\s+(\S*ekf_cov_update_mfma_f32\S*)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", text)
     assert all(int(b) == 0 for _, b in scratch), scratch
+    # the macro-tile kernel counts its LDS-DMAs and P loads by hand too (scratch accesses would sit in the same counter)
+    out2 = tmp_path / "macro.s"
+    subprocess.run([_build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                    str(_build.CSRC / "ekf_cov_macro.hip"), "-o", str(out2)], check=True, capture_output=True)
+    text2 = out2.read_text()
+    macro = re.findall(r"\.name:\s+(\S*ekf_cov_update_macro_f32\S*)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", text2)
+    assert len(macro) >= 24 and all(int(b) == 0 for _, b in macro), macro
 
 
 def test_hand_issued_loads_are_not_touched_before_their_wait(tmp_path):
