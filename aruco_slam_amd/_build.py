@@ -11,7 +11,7 @@ CSRC = PKG / "csrc"
 LIB_DIR = PKG / "lib"
 LIB_PATH = LIB_DIR / "libekf_slam_hip.so"
 SOURCES = ["ekf_api.hip", "ekf_small_kernels.hip", "ekf_front.hip", "ekf_front_f64.hip", "ekf_cov_update.hip", "ekf_cov_macro.hip", "ekf_pose_ippe.hip"]
-HEADERS = ["ekf_device.h", "ekf_kernels.h", "ekf_solve_device.h", "ekf_front_impl.h", "../../include/ekf_slam_hip.h"]
+HEADERS = ["ekf_device.h", "ekf_kernels.h", "ekf_solve_device.h", "ekf_solve_big.h", "ekf_front_impl.h", "../../include/ekf_slam_hip.h"]
 
 
 def hipcc() -> str:

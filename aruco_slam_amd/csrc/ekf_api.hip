@@ -137,8 +137,8 @@ int check_config(const ekf_config* c) {
     if (c->max_landmarks < 1) return fail(EKF_ERR_INVALID, "max_landmarks must be >= 1");
     if (c->model != EKF_MODEL_EKF && c->model != EKF_MODEL_ROTATIONS)
         return fail(EKF_ERR_INVALID, "unknown model");
-    if (c->max_visible < 1 || c->max_visible > (c->model == EKF_MODEL_ROTATIONS ? 27 : 64))
-        return fail(EKF_ERR_INVALID, "max_visible must be in 1..64 (1..27 for EKF_MODEL_ROTATIONS)");
+    if (c->max_visible < 1 || c->max_visible > (c->model == EKF_MODEL_ROTATIONS ? 50 : 64))
+        return fail(EKF_ERR_INVALID, "max_visible must be in 1..64 (1..50 for EKF_MODEL_ROTATIONS)");
     if (c->cov_dtype != EKF_COV_F64 && c->cov_dtype != EKF_COV_F32)
         return fail(EKF_ERR_INVALID, "cov_dtype must be EKF_COV_F64 or EKF_COV_F32");
     if (c->quat_mode != EKF_QUAT_AS_WRITTEN && c->quat_mode != EKF_QUAT_SCALAR_FIRST)
@@ -273,7 +273,9 @@ EkfFrame make_frame(ekf_filter* f, const int32_t* idx_dev, const double* z_dev, 
 }
 
 // Fused front kernel or the three stage kernels?  Fused unless the caller opted out (flags bit 2).
-bool use_front_kernel(const ekf_filter* f, const EkfFrame&) { return (f->cfg.flags & 4) == 0; }
+// Beyond k = 192 rows (EKF_Rotations with more than 27 markers in view) the frame runs through the stage kernels: the fused
+// kernel's chunk and S-block roles are laid out for at most twelve block columns.
+bool use_front_kernel(const ekf_filter* f, const EkfFrame& fr) { return (f->cfg.flags & 4) == 0 && fr.kpad <= 192; }
 
 // Exchange buffers of a FUSED frame.  Parity, frame tag and the chunk counter advance with the fused
 // frames only: a stage-kernel frame neither uses nor re-arms the exchange, so a filter may alternate
@@ -800,7 +802,7 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
     const int kpad_now = (int)round_up(f->lay.rd * m, EKF_RB);
     const bool auto_on = dims_now >= 200 && !(dims_now > 9000 && kpad_now > 96);
     const bool want = (f->cfg.flags & 2) != 0 || ((f->cfg.flags & 1) == 0 && auto_on);
-    bool pipelined = want && f->lay.has_cov2 && !f->timing && frames >= 2 && (f->cfg.flags & 4) == 0;
+    bool pipelined = want && f->lay.has_cov2 && !f->timing && frames >= 2 && (f->cfg.flags & 4) == 0 && kpad_now <= 192;
     if (pipelined && f->la_ok < 0) {
         // The device-side gates need the two streams on DIFFERENT hardware queues (HIP maps streams to a small pool
         // of queues): a gate that shares its queue with the launch it waits for would wait for ever.  Probe once: a

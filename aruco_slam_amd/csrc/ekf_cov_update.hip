@@ -414,8 +414,10 @@ void ekf_launch_cov_update<float>(const EkfFrame& fr, int variant, hipStream_t s
             // (tests/test_host_cpu.py checks the spill count of every instantiation).
 #define EKF_COV_CASE(KB) case KB: EKF_COV_LAUNCH((ekf_cov_update_mfma_f32<KB, 3, (KB <= 8) ? 5 : 4>), grid, block, s, e0, e1, fr, items); break;
             EKF_COV_CASE(1) EKF_COV_CASE(2) EKF_COV_CASE(3) EKF_COV_CASE(4) EKF_COV_CASE(5) EKF_COV_CASE(6)
-            EKF_COV_CASE(7) EKF_COV_CASE(8) EKF_COV_CASE(9) EKF_COV_CASE(10) EKF_COV_CASE(11)
-            default: EKF_COV_LAUNCH((ekf_cov_update_mfma_f32<12, 3, 4>), grid, block, s, e0, e1, fr, items); break;
+            EKF_COV_CASE(7) EKF_COV_CASE(8) EKF_COV_CASE(9) EKF_COV_CASE(10) EKF_COV_CASE(11) EKF_COV_CASE(12)
+            EKF_COV_CASE(13) EKF_COV_CASE(14) EKF_COV_CASE(15) EKF_COV_CASE(16) EKF_COV_CASE(17) EKF_COV_CASE(18)
+            EKF_COV_CASE(19) EKF_COV_CASE(20) EKF_COV_CASE(21) EKF_COV_CASE(22) EKF_COV_CASE(23) EKF_COV_CASE(24)
+            default: break;      // (check_config keeps kpad <= 384)
 #undef EKF_COV_CASE
         }
     }

@@ -43,7 +43,7 @@
 // Arithmetic and its order are those of the stand-alone gather / solve / panel kernels
 // (ekf_small_kernels.hip): results are bitwise identical (tests/test_hip_parity.py).
 #pragma once
-#include "ekf_solve_device.h"
+#include "ekf_solve_big.h"
 
 #define FR_T 512
 #define FR_ALD 66          // row stride (doubles) of the A chunk in LDS
@@ -476,6 +476,21 @@ struct SvIoFused {
             stale |= fr_tag_stale(ekf_ldc(fr.xl + fr.xl_tag + 16), fr.seqno);
         }
     }
+    // (ekf_solve_big.h) one complete S block: all four words requested, then fetched again until every word has landed; its tag
+    __device__ __forceinline__ sf64x4 fetch_block(int i, int tc, int lane) {
+        const double* p0 = fr.xs + sv_blk_index(i, tc) + 2 * lane;
+        const double tag = ekf_ldc(fr.xs_tag + 16 * tc + i);
+        sf64x4 v = {ekf_ldc(p0), ekf_ldc(p0 + 1), ekf_ldc(p0 + 128), ekf_ldc(p0 + 129)};
+        stale |= fr_tag_stale(tag, fr.seqno);
+        settle_block(v, i, tc, lane);
+        return v;
+    }
+    // a finished block of the factor read back from the exchange: -L_iq in `lop` order (the caller has seen the publisher's
+    // "column q is in memory"; coherent loads)
+    __device__ __forceinline__ sf64x4 hist_block(int i, int q, int lane) const {
+        const double* base = fr.xl + sv_lop_index(i, q) + lane;
+        return sf64x4{ekf_ldc(base), ekf_ldc(base + 64), ekf_ldc(base + 128), ekf_ldc(base + 192)};
+    }
     __device__ __forceinline__ void put_dinv(int b, const sf64x4& xop, int lane) {
         double* xdop = fr.xl + fr.xl_dop;
 #pragma unroll
@@ -497,7 +512,7 @@ __device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, double* v_sm)
     if (fr.stamps && tid == 0) fr.stamps[62] = wall_clock64();
     SvIoFused io{fr, 0, 0};
     int bad = 0, badcol = 0;
-    sv_factor<NB>(fr, io, v_sm, bad, badcol);
+    sv_factor_any<NB>(fr, io, v_sm, bad, badcol);
     if ((bad | io.spin_fail | io.stale) && lane == 0) {
         ekf_raise(fr, (bad ? EKF_ST_NOT_SPD : 0) | (io.spin_fail ? EKF_ST_TIMEOUT : 0) | (io.stale ? EKF_ST_STALE_S : 0));
         if (bad) {      // diagnostics: which wave saw it, and the first block column
@@ -1163,7 +1178,7 @@ static void ekf_front_go(const EkfFrame& fr, hipStream_t s) {
                                          : (size_t)(16 * ((NSLOT + 15) / 16)) * (16 * ((NSLOT + 15) / 16)) * 8;
     const size_t lds_s = ((size_t)fr.k * JC + NSLOT * 16 + 32 + fr.kpad) * 8 + 16 + (fix ? dots_b : 0);
     const size_t lds_c = ((size_t)fr.k * JC + fr_chunk_a_len(fr.kpad, fix, (int)sizeof(T))) * 8 + 72 * 4 + 8 * 64 * 8 + 64 * 8 + 64 * 4 + 16;
-    const size_t lds_f = (size_t)sv_lds_doubles(NB) * 8;
+    const size_t lds_f = (size_t)sv_lds_doubles_any(NB) * 8;
     size_t lds = lds_s > lds_c ? lds_s : lds_c;
     if (lds_f > lds) lds = lds_f;
     if ((size_t)fr.lds_min > lds) lds = (size_t)fr.lds_min;

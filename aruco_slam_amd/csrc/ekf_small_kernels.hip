@@ -168,7 +168,8 @@ void ekf_launch_gather(const EkfFrame& fr, hipStream_t s) {
     const dim3 grid(fr.ncols / 64 + nb * (nb + 1) / 2);
     if (fr.model == 1) {        // EKF_Rotations: 7 rows / detection, m <= 27
         const size_t lds = ((size_t)fr.k * 20 + (EKF_CAM + 10 * 4) * 16) * sizeof(double) + (size_t)fr.m * sizeof(int) + 16;
-        hipLaunchKernelGGL((ekf_gather_kernel<T, 8, 1>), grid, dim3(256), lds, s, fr);
+        if (fr.m <= 32) hipLaunchKernelGGL((ekf_gather_kernel<T, 8, 1>), grid, dim3(256), lds, s, fr);
+        else hipLaunchKernelGGL((ekf_gather_kernel<T, 13, 1>), grid, dim3(256), lds, s, fr);      // up to 52 detections
         return;
     }
     const size_t lds = ((size_t)fr.k * EKF_JCOLS + 31 * 16) * sizeof(double) + (size_t)fr.m * sizeof(int) + 16;
@@ -183,7 +184,7 @@ template void ekf_launch_gather<double>(const EkfFrame&, hipStream_t);
 // --------------------------------------------------------------------------
 // solve
 // --------------------------------------------------------------------------
-#include "ekf_solve_device.h"
+#include "ekf_solve_big.h"
 
 // One workgroup: the shared register-resident factorisation (ekf_solve_device.h: sv_factor) with the
 // plain IO policy.  One instantiation per block count NB = kpad / 16.
@@ -192,28 +193,30 @@ __global__ __launch_bounds__(SV_T) void ekf_solve_kernel(EkfFrame fr) {
     extern __shared__ __attribute__((aligned(16))) double v_sm[];
     SvIoPlain io{fr};
     int bad = 0, badcol = 0;
-    sv_factor<NB>(fr, io, v_sm, bad, badcol);
+    sv_factor_any<NB>(fr, io, v_sm, bad, badcol);
     if (bad && (threadIdx.x & 63) == 0) ekf_raise(fr, EKF_ST_NOT_SPD);
 }
 
 template <int NB>
 static void ekf_solve_go(const EkfFrame& fr, hipStream_t s) {
-    hipLaunchKernelGGL(ekf_solve_kernel<NB>, dim3(1), dim3(SV_T), sv_lds_doubles(NB) * sizeof(double), s, fr);
+    if (sv_lds_doubles_any(NB) * sizeof(double) > 64 * 1024) {      // > 64 KB of dynamic LDS needs the opt-in
+        static bool once = false;
+        if (!once) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ekf_solve_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)(sv_lds_doubles_any(NB) * sizeof(double)));
+            once = true;
+        }
+    }
+    hipLaunchKernelGGL(ekf_solve_kernel<NB>, dim3(1), dim3(SV_T), sv_lds_doubles_any(NB) * sizeof(double), s, fr);
 }
 void ekf_launch_solve(const EkfFrame& fr, hipStream_t s) {
     switch (fr.kpad / EKF_RB) {
-        case 1: return ekf_solve_go<1>(fr, s);
-        case 2: return ekf_solve_go<2>(fr, s);
-        case 3: return ekf_solve_go<3>(fr, s);
-        case 4: return ekf_solve_go<4>(fr, s);
-        case 5: return ekf_solve_go<5>(fr, s);
-        case 6: return ekf_solve_go<6>(fr, s);
-        case 7: return ekf_solve_go<7>(fr, s);
-        case 8: return ekf_solve_go<8>(fr, s);
-        case 9: return ekf_solve_go<9>(fr, s);
-        case 10: return ekf_solve_go<10>(fr, s);
-        case 11: return ekf_solve_go<11>(fr, s);
-        default: return ekf_solve_go<12>(fr, s);
+#define SV_CASE(NB) case NB: return ekf_solve_go<NB>(fr, s);
+        SV_CASE(1) SV_CASE(2) SV_CASE(3) SV_CASE(4) SV_CASE(5) SV_CASE(6) SV_CASE(7) SV_CASE(8) SV_CASE(9) SV_CASE(10) SV_CASE(11)
+        SV_CASE(12) SV_CASE(13) SV_CASE(14) SV_CASE(15) SV_CASE(16) SV_CASE(17) SV_CASE(18) SV_CASE(19) SV_CASE(20) SV_CASE(21)
+        SV_CASE(22) SV_CASE(23) SV_CASE(24)
+#undef SV_CASE
+        default: return;      // (check_config keeps kpad <= 384)
     }
 }
 
@@ -305,18 +308,12 @@ static void ekf_panel_mfma_go(const EkfFrame& fr, hipStream_t s) {
 template <typename T>
 void ekf_launch_panel(const EkfFrame& fr, hipStream_t s) {
     switch (fr.kpad / EKF_RB) {
-        case 1: return ekf_panel_mfma_go<T, 1>(fr, s);
-        case 2: return ekf_panel_mfma_go<T, 2>(fr, s);
-        case 3: return ekf_panel_mfma_go<T, 3>(fr, s);
-        case 4: return ekf_panel_mfma_go<T, 4>(fr, s);
-        case 5: return ekf_panel_mfma_go<T, 5>(fr, s);
-        case 6: return ekf_panel_mfma_go<T, 6>(fr, s);
-        case 7: return ekf_panel_mfma_go<T, 7>(fr, s);
-        case 8: return ekf_panel_mfma_go<T, 8>(fr, s);
-        case 9: return ekf_panel_mfma_go<T, 9>(fr, s);
-        case 10: return ekf_panel_mfma_go<T, 10>(fr, s);
-        case 11: return ekf_panel_mfma_go<T, 11>(fr, s);
-        default: return ekf_panel_mfma_go<T, 12>(fr, s);
+#define PN_CASE(NB) case NB: return ekf_panel_mfma_go<T, NB>(fr, s);
+        PN_CASE(1) PN_CASE(2) PN_CASE(3) PN_CASE(4) PN_CASE(5) PN_CASE(6) PN_CASE(7) PN_CASE(8) PN_CASE(9) PN_CASE(10) PN_CASE(11)
+        PN_CASE(12) PN_CASE(13) PN_CASE(14) PN_CASE(15) PN_CASE(16) PN_CASE(17) PN_CASE(18) PN_CASE(19) PN_CASE(20) PN_CASE(21)
+        PN_CASE(22) PN_CASE(23) PN_CASE(24)
+#undef PN_CASE
+        default: return;
     }
 }
 template void ekf_launch_panel<float>(const EkfFrame&, hipStream_t);

@@ -326,6 +326,13 @@ struct SvIoPlain {
             else if (has1 && i1 < NB && tc >= C0 && tc < C1 && tc <= i1) z1[tc] = load_block(i1, tc, lane);
         }
     }
+    // (ekf_solve_big.h) complete blocks of S / the residual, and a finished block of the factor read back: -L_iq in `lop` order
+    __device__ __forceinline__ sf64x4 fetch_block(int i, int tc, int lane) const { return load_block(i, tc, lane); }
+    __device__ __forceinline__ sf64x4 fetch_resid(int tc, int g) const { return load_resid(tc, g); }
+    __device__ __forceinline__ sf64x4 hist_block(int i, int q, int lane) const {
+        const double* base = fr.lop + sv_lop_index(i, q) + lane;
+        return sf64x4{ekf_ldc(base), ekf_ldc(base + 64), ekf_ldc(base + 128), ekf_ldc(base + 192)};
+    }
     __device__ __forceinline__ void put_dinv(int b, const sf64x4& xop, int lane) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

@@ -55,7 +55,7 @@ class EKF_Rotations(BaseFilter):  # noqa: N801  (name of the reference class)
         if max_landmarks is None:
             max_landmarks = dictionary_size(None)    # (the reference's EKF_Rotations takes no aruco_dict: DICT_5X5_50)
         if max_visible is None:
-            max_visible = min(max_landmarks, 27)     # 7 rows per detection, k <= 192
+            max_visible = min(max_landmarks, 27)     # 7 rows per detection, k <= 192: the fused front kernel (grows to 50)
         self._hip = HipEkf(max_landmarks, max_visible, cov_dtype=cov_dtype, quat_mode="scalar_first",
                            cov_kernel=cov_kernel, device=device, lookahead=lookahead, fused=fused,
                            model="ekf_rotations",

@@ -133,7 +133,7 @@ class HipEkf:
     """One filter instance = one C handle + the torch tensors it borrows."""
 
     KERNEL_NAMES = ("gather", "solve", "panel", "cov_update")
-    MAX_VISIBLE_LIMIT = {3: 64, 10: 27}      # detections per frame the kernels take (by landmark width: EKF / EKF_Rotations)
+    MAX_VISIBLE_LIMIT = {3: 64, 10: 50}      # detections per frame the kernels take (by landmark width: EKF / EKF_Rotations)
 
     def __init__(self, max_landmarks: int, max_visible: int, cov_dtype="float64",
                  quat_mode="as_written", cov_kernel="auto", device="cuda:0", noise=None,

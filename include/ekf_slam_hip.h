@@ -62,7 +62,8 @@ enum {
 
 typedef struct ekf_config {
     int32_t max_landmarks;  /* capacity n_max */
-    int32_t max_visible;    /* max observations per frame (<= 64; <= 27 for EKF_MODEL_ROTATIONS) */
+    int32_t max_visible;    /* max observations per frame (<= 64; <= 50 for EKF_MODEL_ROTATIONS: k = 7 m <= 350 rows; beyond k = 192
+                             * the frame runs through the stage kernels, in serial order) */
     int32_t cov_dtype;      /* EKF_COV_F64 / EKF_COV_F32 */
     int32_t quat_mode;      /* EKF_QUAT_* */
     int32_t cov_kernel;     /* EKF_COVK_*: covariance-update kernel */

@@ -1142,3 +1142,27 @@ def test_only_one_handle_of_a_process_pipelines_at_a_time():
     ref.backend.observe_sequence(data[1][0][:4], data[1][1][:4])
     assert np.array_equal(ref.state, b.state)
     assert np.array_equal(ref.uncertainty, b.uncertainty)
+
+
+def test_rotations_with_all_50_markers_of_the_dictionary_in_view_vs_oracle():
+    """EKF_Rotations with every marker of DICT_5X5_50 detected in a frame: k = 7 x 50 = 350 measurement rows, 22 block
+    columns of S (the reference takes any number of detections, ekf_with_rotations.py:115-181; rounds 1 - 2 stopped at 27).
+    The streamed factorisation (csrc/ekf_solve_big.h) through the stage kernels, f64, against the oracle; the filter was
+    built for 27 detections per frame and grows."""
+    from aruco_slam_amd.synthetic import SyntheticStream
+    from oracle.ekf_numpy import OracleEKFRotations
+    n, m = 60, 50
+    s = SyntheticStream(n, m, seed=21, rvec_sigma=0.05)
+    flt = _rot(max_landmarks=n, cov_dtype="float64")
+    orc = OracleEKFRotations(INIT, mode="fast")
+    worst = np.zeros(2)
+    frames = list(s.bootstrap()) + list(s.steady(6))
+    for ids, poses in frames:
+        flt.observe(ids, poses)
+        orc.observe(list(ids), poses)
+        worst = np.maximum(worst, [rel_err(flt.state, orc.state), rel_err(flt.uncertainty, orc.uncertainty)])
+    assert flt.backend.max_visible >= 50
+    report("rotations_k350[float64]", state=worst[0], cov=worst[1])
+    assert worst[0] <= 1e-9 and worst[1] <= 1e-9, worst
+    p = flt.uncertainty
+    assert np.array_equal(p, p.T)
