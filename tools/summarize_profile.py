@@ -26,8 +26,8 @@ ap.add_argument("src")
 ap.add_argument("tag")
 ap.add_argument("--key", default="n1024_m32_float32")
 ap.add_argument("--steady", type=int, default=100, help="launches to average: the instrumented serial-order repeat of bench.py")
-ap.add_argument("--skip-last", type=int, default=250,
-                help="launches at the very end that are left out (bench.py ends with 250 per-frame observes through the host boundary, "
+ap.add_argument("--skip-last", type=int, default=450,
+                help="launches at the very end that are left out (bench.py ends with 450 per-frame observes through the host boundary, "
                      "whose front kernel also reads the detections from / mirrors the state to host memory)")
 ap.add_argument("--parity", default=None, help="parity_metrics.jsonl of the same session to keep next to the profile")
 args = ap.parse_args()
@@ -47,14 +47,16 @@ def window(v):
     return w or v
 steady = {k: sum(window(v)) / len(window(v)) / 1e3 for k, v in dur.items()}
 
+# the covariance-update kernel of the steady state: the one of the window's launches (bootstrap frames of a large
+# configuration run smaller instantiations / the other kernel)
+cov_name = max((k for k in steady if "cov_update" in k), key=lambda k: len(dur[k]) * steady[k])
 pmc = {}
 for kind, name in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     f = glob.glob(str(src / kind / "*" / "*counter_collection.csv"))[0]
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-            if "cov_update" in r["Kernel_Name"] and r["Counter_Name"] == name]
+            if r["Kernel_Name"] == cov_name and r["Counter_Name"] == name]
     pmc[name] = sum(window(vals)) / len(window(vals))
 traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
-cov_name = next(k for k in steady if "cov_update" in k)
 bench_args = (src / "bench_args.txt").read_text().strip() if (src / "bench_args.txt").exists() else "--cpu-frames 0 --steps 100 --warmup 10"
 summary = {
     "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py " + bench_args,
