@@ -92,8 +92,7 @@ Layout make_layout(const ekf_config& c) {
     L.off_wpanel2 = take((size_t)L.kmax * L.cap * L.elem);
     // pipelined sequence mode (MFMA update, fused front kernel): the second covariance buffer
     // (P_t is read, P_{t+1} written elsewhere, so that the next front kernel can read P_t beside the update)
-    L.has_cov2 = c.cov_kernel != EKF_COVK_VALU && (c.flags & 5) == 0 &&
-                 ((c.flags & 2) != 0 || L.cap >= 256);
+    L.has_cov2 = c.cov_kernel != EKF_COVK_VALU && (c.flags & 5) == 0;
     L.off_cov2 = L.has_cov2 ? take((size_t)L.cap * L.cap * L.elem) : 0;
     L.off_wdbg = take((size_t)L.kmax * L.cap * 8);
     L.off_idx = take((size_t)c.max_visible * 4);
@@ -325,8 +324,10 @@ int ensure_tiles(ekf_filter* f) {
 }
 
 // predict + update for one frame: the front kernel (or gather / solve / panel) and the covariance update
+// `mirror`: the frame also leaves its state in the pinned host mirror (per-frame entry points: a state getter usually follows;
+// frames of a sequence call do not -- no getter can run between them, and the mirror is 8 N bytes over PCIe per frame)
 int enqueue_frame(ekf_filter* f, const int32_t* idx_dev, const double* z_dev, int m,
-                  double* traj_row) {
+                  double* traj_row, bool mirror) {
     int trc = ensure_tiles(f);
     if (trc) return trc;
     EkfFrame fr = make_frame(f, idx_dev, z_dev, m, traj_row);
@@ -347,7 +348,7 @@ int enqueue_frame(ekf_filter* f, const int32_t* idx_dev, const double* z_dev, in
     if (use_front_kernel(f, fr)) {
         // one launch: timing slot 0 = the whole front kernel, slots 1 and 2 stay empty
         bind_exchange(f, fr);
-        if (!f->timing) {
+        if (!f->timing && mirror) {
             fr.state_host = reinterpret_cast<double*>(f->readback + 256);
             fr.status_host = reinterpret_cast<int32_t*>(f->readback + 128);
             f->mirror_fresh = true;
@@ -763,7 +764,7 @@ int ekf_observe(ekf_filter* f, const int32_t* lm_index, const double* z, int32_t
     // The kernels read the frame's detections (128 + 768 bytes at m = 32) straight from the pinned slot: a host-to-device
     // copy in front of them costs more (API call + DMA start, ~8 us before the front kernel begins) than the PCIe reads
     // cost the kernel's first round trip.  The slot is not reused before this frame's event (64-slot ring).
-    rc = enqueue_frame(f, hidx, hz, m, nullptr);
+    rc = enqueue_frame(f, hidx, hz, m, nullptr, true);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(f->slot_done[f->slot], f->stream));
     f->slot = (f->slot + 1) % kStageSlots;
@@ -778,7 +779,7 @@ int ekf_observe_device(ekf_filter* f, const int32_t* lm_index_dev, const double*
     if (!lm_index_dev || !z_dev) return fail(EKF_ERR_INVALID, "NULL detections");
     if (f->n_lm < 1) return fail(EKF_ERR_STATE, "observe before any landmark was added");
     // the indices are device-resident: range-checked by the kernels (EKF_ERR_INVALID at the next sync)
-    return enqueue_frame(f, lm_index_dev, z_dev, m, nullptr);
+    return enqueue_frame(f, lm_index_dev, z_dev, m, nullptr, true);
 }
 
 int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, const double* z_dev,
@@ -789,18 +790,19 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
     if (m > f->cfg.max_visible) return fail(EKF_ERR_CAPACITY, "more detections than max_visible");
     if (!lm_index_dev || !z_dev) return fail(EKF_ERR_INVALID, "NULL detections");
     if (f->n_lm < 1) return fail(EKF_ERR_STATE, "observe before any landmark was added");
-    // Pipelined mode (F(t+1) beside C(t), see below): flags bit 1 forces it, bit 0 forbids it, otherwise it is
-    // chosen where it was measured to win (tools/pipeline_sweep.py).  MFMA covariance update (f32 or f64) and the
-    // fused front kernel only.
-    // (tools/pipeline_sweep.py, us per frame pipelined / serial: n=64 m=8 12.9 / 18.5 - n=128 m=8 18.2 / 18.2 -
-    // n=128 m=16 15.3 / 21.2 - n=256 m=16 15.1 / 21.0 - n=512 m=16 15.0 / 22.0 - n=512 m=32 22.8 / 31.1 -
-    // n=1024 m=32 24.2 / 38.9 - n=1024 m=64 110 / 132 - n=2048 m=32 62.4 / 71.9 - n=2048 m=64 126 / 187 -
-    // n=4096 m=32 238 / 249 - n=4096 m=64 468 / 442: there the front kernel's 273 workgroups hold every CU while they
-    // wait for the factorisation, and the update cannot run beside them; f64: n=64 m=8 13.2 / 18.8 - n=256 m=16 16.3 / 21.7
-    // - n=1024 m=32 44.4 / 54.7)
+    // Pipelined mode (F(t+1) beside C(t), see below): flags bit 1 forces it, bit 0 forbids it, otherwise it is chosen where it
+    // was measured to win.  MFMA covariance update (f32 or f64) and the fused front kernel only.
+    // tools/mode_select.py (profiles/r03_mode_select.txt: 2000 frames per call after a warm-up call, start-to-start of the
+    // front kernels on the device clock, pipelined / serial in us per frame): n=32 m=3 11.1 / 16.1 - n=64 m=8 12.5 / 18.5 -
+    // n=128 m=16 15.5 / 21.7 - C2 (n=256 m=16 f64) 15.9 / 21.5 - n=512 m=32 22.8 / 31.6 - n=1024 m=32 24.2 / 39.3: it wins at
+    // every shape down to the smallest.  (Round 2's soak tool had it slower at C2: its timed region began with the handle's
+    // very first pipelined call, which holds the one-time queue self-test.)  tools/pipeline_sweep.py, larger shapes:
+    // n=1024 m=64 81.8 / 95.1 - n=2048 m=32 61.7 / 73.3 - n=2048 m=64 115.7 / 152.4 - n=4096 m=32 237 / 238 - n=4096 m=64
+    // 398 / 371: there the front kernel's 273 workgroups hold every CU while they wait for the factorisation, and the update
+    // cannot run beside them.
     const int dims_now = f->dims();
     const int kpad_now = (int)round_up(f->lay.rd * m, EKF_RB);
-    const bool auto_on = dims_now >= 200 && !(dims_now > 9000 && kpad_now > 96);
+    const bool auto_on = !(dims_now > 9000 && kpad_now > 96);
     const bool want = (f->cfg.flags & 2) != 0 || ((f->cfg.flags & 1) == 0 && auto_on);
     bool pipelined = want && f->lay.has_cov2 && !f->timing && frames >= 2 && (f->cfg.flags & 4) == 0 && kpad_now <= 192;
     if (pipelined && f->la_ok < 0) {
@@ -852,7 +854,7 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
     if (!pipelined) {
         for (int t = 0; t < frames; ++t) {
             rc = enqueue_frame(f, lm_index_dev + (size_t)t * m, z_dev + (size_t)t * m * f->lay.rd, m,
-                               trajectory_dev ? trajectory_dev + (size_t)t * 7 : nullptr);
+                               trajectory_dev ? trajectory_dev + (size_t)t * 7 : nullptr, false);
             if (rc) return rc;
         }
         return EKF_OK;

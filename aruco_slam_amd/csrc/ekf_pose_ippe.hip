@@ -18,6 +18,10 @@
 //      rvec = axis * angle of the rotation.
 // No fixture of the reference pins these numbers ("parity unpinned"): tests compare the kernel with a NumPy
 // restatement of the same steps (oracle/ippe_numpy.py) and with the poses the corners were projected from.
+// One KNOWN structural difference to the reference's call: base_filter.py passes float32 corners and object points, and
+// cv::undistortPoints returns CV_32F for float32 input, so OpenCV's normalised points are rounded to f32 before IPPE;
+// this kernel stays in f64 throughout.  Expect ~1e-7 relative differences in tvec / rvec against a cv2 run (the
+// as-written EKF amplifies such differences over long free runs: SURVEY F5).
 #include "ekf_kernels.h"
 
 namespace {

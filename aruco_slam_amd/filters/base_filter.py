@@ -108,7 +108,9 @@ class BaseFilter:
         from aruco_slam_amd import hip_backend
         if len(ids) == 0:
             return np.zeros((0, 6))
-        return hip_backend.estimate_poses(corners, marker_size, self.calib_matrix, self.dist_coeffs)
+        backend = getattr(self, "_hip", None)        # (the filter's own GPU: one sequence per GPU)
+        device = str(backend.device) if backend is not None else "cuda:0"
+        return hip_backend.estimate_poses(corners, marker_size, self.calib_matrix, self.dist_coeffs, device=device)
 
     def process_frame(self, frame, should_filter=True, iteration=0, marker_size=0.16):
         """base_filter.py:173-212."""

@@ -71,8 +71,8 @@ typedef struct ekf_config {
     int32_t reserved;
     int32_t flags;          /* bits 0-1: pipelined mode of ekf_observe_sequence_device (the front kernel of frame t+1 runs
                              * beside the covariance update of frame t; same results, bit for bit): 0 = chosen by size
-                             * (MFMA covariance update only, either dtype; on from 200 state dimensions, except
-                             * above 9000 with more than 32 detections per frame), bit 0 = never, bit 1 = always.  Unless bit 0
+                             * (MFMA covariance update only, either dtype; on except above 9000 state dimensions
+                             * with more than 32 detections per frame), bit 0 = never, bit 1 = always.  Unless bit 0
                              * is set, a capable configuration adds a second covariance buffer to the workspace
                              * (ekf_query_sizes: + ld^2 elements).  One handle per process pipelines at a time
                              * (ekf_last_sequence_mode).
