@@ -60,6 +60,10 @@ __host__ __device__ inline size_t fr_chunk_a_len(int kpad, bool fix, int elem) {
     const size_t st = elem == 4 ? (size_t)(FR_KS * 128 + FR_KS * 64 + 128 * 64) / 2 : (size_t)(2 * FR_KS64 * 64 + 64 * 64);
     return (fix && a < st) ? st : a;
 }
+// NB > 8 (k > 128): the four waves that do not substitute fetch whole block columns of the factor into LDS slots instead
+// (fr_panel_stage), see fr_panel.
+#define FR_STAGED_MIN_NB 9
+#define FR_SLOTS 4
 
 typedef double pf64x4 __attribute__((ext_vector_type(4)));
 // Stores of W / W_sup (read by later launches only): write-through, like the covariance update's (ekf_cov_update.hip) --
@@ -543,6 +547,8 @@ __device__ __forceinline__ void fr_role_factor(const EkfFrame& fr, double* v_sm)
 // slots its column feeds.  A word that has not been published yet arrives as the sentinel and is fetched again.
 template <int NB>
 struct FrPre {
+    static constexpr bool STAGED = NB >= FR_STAGED_MIN_NB;
+    static constexpr int SLOT = NB * 256 + 16;      // doubles per staged block column: Dinv | -L blocks below the diagonal | y
     static constexpr int LG = (NB >= 11) ? 4 : 6;
     double lqa[LG][4], dqn[4], yqn[4];
     unsigned long long smask;       // next-frame detections whose landmark owns this lane's column (duplicates possible)
@@ -552,18 +558,103 @@ template <int NB, int MODEL>
 __device__ __forceinline__ void fr_panel_pre(const EkfFrame& fr, FrPre<NB>& pre, const unsigned long long* smask_l, int wv, int col0, int lane) {
     const int j = lane & 15, g = lane >> 4;
     const double* __restrict__ xlop = fr.xl;
+    if constexpr (!FrPre<NB>::STAGED) {
 #pragma unroll
-    for (int i = 1; i < NB && i < 1 + FrPre<NB>::LG; ++i)
+        for (int i = 1; i < NB && i < 1 + FrPre<NB>::LG; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pre.lqa[i - 1][r] = ekf_ldc(xlop + sv_lop_index(i, 0) + r * 64 + lane);
+            for (int r = 0; r < 4; ++r) pre.lqa[i - 1][r] = ekf_ldc(xlop + sv_lop_index(i, 0) + r * 64 + lane);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        pre.dqn[r] = (wv == 0) ? ekf_ldc(fr.xl + fr.xl_dop + (size_t)r * 64 + lane) : 0.0;
-        pre.yqn[r] = (wv == 0) ? ekf_ldc(fr.xl + fr.xl_y + g + 4 * r) : 0.0;
+        for (int r = 0; r < 4; ++r) {
+            pre.dqn[r] = (wv == 0) ? ekf_ldc(fr.xl + fr.xl_dop + (size_t)r * 64 + lane) : 0.0;
+            pre.yqn[r] = (wv == 0) ? ekf_ldc(fr.xl + fr.xl_y + g + 4 * r) : 0.0;
+        }
     }
     const int mycol = col0 + j;
     pre.smask = fr.wsup ? smask_l[16 * wv + j] : 0ull;
     pre.sdim = (mycol >= EKF_CAM) ? (mycol - EKF_CAM) % EkfModel<MODEL>::LMD : 0;
+}
+
+// Staged substitution (NB >= FR_STAGED_MIN_NB), the waves 4 .. 7 of a chunk workgroup: wave w fetches the block columns
+// q = w, w + 4, w + 8 .. of the factor -- Dinv_q and y_q, then the -L_iq below them: four columns in flight per
+// workgroup -- polls until every word has been published (sentinel), and puts the column into slot
+// q % FR_SLOTS of the A-chunk region of LDS (free once the substituting waves hold their columns of A in registers: the
+// barrier).  flags[s] = columns whose Dinv / y have been placed in slot s so far, flags[8 + s] = whose -L blocks have,
+// flags[4 + s] = reads of slot s acknowledged (4 per column).
+// Before: every substituting wave fetched its own copy of -L in groups of four blocks, a dependent round trip per group
+// (22 per chunk at NB = 12: with everything published the twelve steps took ~60 us; staged: 13 us after the first column's
+// round trip.  Pipelined n=1024 m=64: 82.4 -> 71.7 us per frame; EKF_Rotations n=400 m=27: 8.43k -> 9.1k updates/s).
+template <int NB>
+__device__ __forceinline__ void fr_panel_stage(const EkfFrame& fr, double* slots, volatile ekf_lds_int* flags, int w, int lane) {
+    constexpr int SLOT = FrPre<NB>::SLOT;
+    const double* __restrict__ xlop = fr.xl;
+    const double* __restrict__ xdop = fr.xl + fr.xl_dop;
+    const double* __restrict__ xy = fr.xl + fr.xl_y;
+    __syncthreads();                                   // the A chunk has been taken into registers
+    int spin_fail = 0;
+    for (int q = w; q < NB; q += 4) {
+        const int cnt = NB - 1 - q;                    // blocks below the diagonal
+        const int sl = q % FR_SLOTS;
+        double* slot = slots + sl * SLOT;
+        // Dinv_q and y_q first (what W_q needs; y is the last thing the factorisation publishes of a column), polled on
+        // these five words per lane only: every chunk polling the bulk -- 24 KB per wave and round -- kept the
+        // factorisation's own stores waiting
+        double dv[4], yv = 0.0;
+        for (int it = 0;; ++it) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dv[r] = ekf_ldc(xdop + (size_t)(q * 4 + r) * 64 + lane);
+            yv = ekf_ldc(xy + 16 * q + (lane & 15));
+            bool pend = ekf_is_sent(yv);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pend = pend || ekf_is_sent(dv[r]);
+            if (!__any(pend)) break;
+            if (it > EKF_SPIN_MAX) { spin_fail = 1; break; }
+            ekf_poll_sleep();
+        }
+        double v[NB - 1][4];
+        auto fetch = [&]() {
+#pragma unroll
+            for (int i = 0; i < NB - 1; ++i) {
+                // (beyond the column's end: the Dinv block once more -- no branch between the loads, always a published word)
+                const double* __restrict__ src = (i < cnt) ? xlop + sv_lop_index(q + 1 + i, q) : xdop + (size_t)q * 256;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[i][r] = ekf_ldc(src + r * 64 + lane);
+            }
+        };
+        fetch();                                       // (in flight while the slot is waited for and Dinv / y go in)
+        if (q >= FR_SLOTS) {                           // the slot's previous column has been read by all four waves
+            int it = 0;
+            while (flags[4 + sl] < 4 * (q / FR_SLOTS)) {
+                if (++it > 64 * EKF_SPIN_MAX) { spin_fail = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slot[r * 64 + lane] = dv[r];
+        if (lane < 16) slot[NB * 256 + lane] = yv;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) flags[sl] = q / FR_SLOTS + 1;
+        for (int it = 0;; ++it) {
+            bool pend = false;
+#pragma unroll
+            for (int i = 0; i < NB - 1; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pend = pend || ekf_is_sent(v[i][r]);
+            if (!__any(pend)) break;
+            if (it > EKF_SPIN_MAX) { spin_fail = 1; break; }
+            ekf_poll_sleep();
+            fetch();
+        }
+#pragma unroll
+        for (int i = 0; i < NB - 1; ++i)
+            if (i < cnt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slot[(1 + i) * 256 + r * 64 + lane] = v[i][r];
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) flags[8 + sl] = q / FR_SLOTS + 1;
+    }
+    if (spin_fail && lane == 0) ekf_raise(fr, EKF_ST_TIMEOUT);
 }
 
 template <typename T, int NB, int MODEL>
@@ -605,7 +696,66 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
     // and (wave 0) its Dinv / y are requested during step q.  A word that has not been published yet reads as the
     // sentinel: such a column goes through the polling path exactly as before.
     constexpr int LG = FrPre<NB>::LG;
-    constexpr bool AHEAD = NB <= 8;                 // two register sets for -L (else: requested at the top of its own step)
+    constexpr bool AHEAD = NB <= 8;                 // two register sets for -L
+    if constexpr (FrPre<NB>::STAGED) {
+        // block columns come through LDS (fr_panel_stage); `pshare` holds the slot flags
+        constexpr int SLOT = FrPre<NB>::SLOT;
+        volatile ekf_lds_int* flags = ekf_lds_flags(pshare);
+        __syncthreads();                               // every wave has its columns of A: the region becomes the slots
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const double* __restrict__ slot = a_lds + (q % FR_SLOTS) * SLOT;
+            int it = 0;
+            while (flags[q % FR_SLOTS] < q / FR_SLOTS + 1) {
+                if (++it > 64 * EKF_SPIN_MAX) { spin_fail = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            double dq[4], yq[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dq[r] = slot[r * 64 + lane];
+                yq[r] = slot[NB * 256 + g + 4 * r];
+            }
+            pf64x4 wq = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wq = __builtin_amdgcn_mfma_f64_16x16x4f64(dq[r], t[q][r], wq, 0, 0, 0);
+            t[q] = wq;
+            if (q + 1 < NB) {
+                it = 0;
+                while (flags[8 + q % FR_SLOTS] < q / FR_SLOTS + 1) {
+                    if (++it > 64 * EKF_SPIN_MAX) { spin_fail = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+#pragma unroll
+            for (int i = q + 1; i < NB; ++i) {
+                double lq[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lq[r] = slot[(i - q) * 256 + r * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(lq[r], wq[r], t[i], 0, 0, 0);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the reads before the acknowledgement
+            if (lane == 0) __hip_atomic_fetch_add(const_cast<ekf_lds_int*>(flags) + 4 + q % FR_SLOTS, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                   // W rows of block q are final
+                const int row = 16 * q + g + 4 * r;
+                fr_w_store(wp + (int64_t)row * fr.ldw + col0 + j, (T)wq[r]);
+                if (fr.wdbg) fr.wdbg[(int64_t)row * fr.ldw + col0 + j] = wq[r];
+                if (cslot >= 0) fr_w_store(wsup + (int64_t)row * fr.wsup_ld + cslot, (T)wq[r]);
+                for (unsigned long long mm = smask; mm; mm &= mm - 1) {
+                    constexpr int LMD = EkfModel<MODEL>::LMD;
+                    const int jj = __builtin_ctzll(mm);
+                    fr_w_store(wsup + (int64_t)row * fr.wsup_ld + EKF_CAM + LMD * jj + sdim, (T)wq[r]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part = __builtin_fma(wq[r], yq[r], part);
+            if (stp) stp[q] = wall_clock64();
+        }
+    } else {
     auto& lqa = pre.lqa;
     auto& dqn = pre.dqn;
     auto& yqn = pre.yqn;
@@ -738,6 +888,7 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
         for (int r = 0; r < 4; ++r) part = __builtin_fma(wq[r], yq[r], part);
         if (stp) stp[q] = wall_clock64();
     }
+    }
     part += __shfl_xor(part, 16);
     part += __shfl_xor(part, 32);                    // dx[col0 + j] in every lane group
     const int col = col0 + j;
@@ -779,6 +930,11 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
     if (wv == 0 && lane == NB && fr_tag_stale(ekf_ldc(fr.xl + fr.xl_tag), fr.seqno)) ekf_raise(fr, EKF_ST_STALE_JAC);
 }
 
+#ifdef FR_CHUNK_DIAG      // (diagnostic builds: prologue stamps of chunk 0 in the slots of the factorisation role)
+#define FR_DIAG(i) do { if (fr.stamps && chunk == 0 && tid == 0) fr.stamps[i] = wall_clock64(); } while (0)
+#else
+#define FR_DIAG(i) do { } while (0)
+#endif
 template <typename T, int NU, int MODEL, int NB>
 __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, double* sm) {
     constexpr int RD = EkfModel<MODEL>::RD, LMD = EkfModel<MODEL>::LMD, JC = EkfModel<MODEL>::JC;
@@ -840,6 +996,7 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
         nidx[tid - 64] = ((unsigned)ni >= (unsigned)fr.n_lm) ? 0 : ni;
     }
     if (tid == 0) { flag[1] = 0; flag[2] = 0; }
+    if (FrPre<NB>::STAGED && tid < 12) ekf_lds_flags(pshare)[tid] = 0;      // (staged substitution: slot flags)
     __syncthreads();
     if (fr.wsup && tid < 64) {      // next-frame detections whose landmark owns column c (duplicates possible)
         unsigned long long mk = 0ull;
@@ -849,6 +1006,7 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
         }
         smask_l[tid] = mk;
     }
+    FR_DIAG(0);
     if (!fix) {
         // (camera rows and landmark rows together: requested before the index round trip, the ten camera-row values
         // were spilled one by one, each load waited for -- hipcc)
@@ -907,8 +1065,10 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
                     const int e = tid + FR_T * n, row = min(e >> 4, rows - 1), c4 = e & 15;
                     vb[n] = *reinterpret_cast<const fr_f4*>(wpb + (int64_t)(16 * kb + row) * fr.ldw + chunk0 + 4 * c4);
                 }
-                if (kb == 0 && tile_ok) {
+                if (kb == 0) {
                     // C / D layout: register reg <-> tile row (reg & 3) + 8 (reg >> 2) + 4 lhi, column l31
+                    // (unconditional -- a tile beyond the last slot reads row 0: inside a branch the wait for the stage's
+                    // operands, which are older, became a wait for these scattered rows as well: 7 us per round at n=4096)
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const int slot = 32 * tile_i + (reg & 3) + 8 * (reg >> 2) + 4 * lhi;
@@ -924,6 +1084,7 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
 #pragma unroll
                 for (int n = 0; n < NBL; ++n) *reinterpret_cast<fr_f4*>(sB + 4 * (tid + FR_T * n)) = vb[n];
                 __syncthreads();
+                FR_DIAG(1 + 4 * round + 2 * (kb / (FR_KS / 16)));
                 if (kb == 0 && round == 0) jac_issue();      // (in flight during the matrix phase)
                 if (stp_c && round == 0 && kb == 0) fr.stamps[45] = wall_clock64();
                 if (tile_ok) {
@@ -937,6 +1098,7 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
                         __builtin_amdgcn_sched_barrier(0);      // (the scheduler would hoist every LDS read of the stage: 16 registers per chunk)
                     }
                 }
+                FR_DIAG(2 + 4 * round + 2 * (kb / (FR_KS / 16)));
             }
             if (stp_c && round == 0) fr.stamps[46] = wall_clock64();
             if (tile_ok) {
@@ -1055,9 +1217,11 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
     // (pipelined mode: requested above, taken only now -- the support rows depend on nothing this launch computes, and
     // fetched "while the first stage is in flight" the Jacobian made the matrix phase wait ~3 us for the measurement
     // workgroup; fetched here as a whole it was 1.6 us of polling and bulk on the way to the A chunk)
+    FR_DIAG(10);
     if (!fix) jac_issue();
     jac_finish();
     __syncthreads();
+    FR_DIAG(11);
     FrPre<NB> pre;
     if (fr.stamps && fr.stamps_heavy && chunk == 0 && tid == 0 && NB <= 6) fr.stamps[14] = wall_clock64();
     // (the support rows become doubles BEFORE the substitution's first requests go out: they may come straight from
@@ -1105,6 +1269,8 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
         const int lane = tid & 63, col0 = chunk0 + 16 * g;
         fr_panel<T, NB, MODEL>(fr, a_lds, ekf_lds_flags(flag + 1), pshare, g, col0, lane, spin_fail, pre);
         if (spin_fail && (tid & 63) == 0) ekf_raise(fr, EKF_ST_TIMEOUT);
+    } else if constexpr (FrPre<NB>::STAGED) {
+        fr_panel_stage<NB>(fr, a_lds, ekf_lds_flags(pshare), g - 4, tid & 63);
     }
     if (MODEL == 0) return;
     // ---- EKF_Rotations: dx of this chunk has to be in memory before the chunk counts as done;

@@ -722,7 +722,7 @@ def test_checkpoint_resume_is_bitwise(tmp_path, make, dtype):
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("make,n,m,dtype", [(_ekf, 24, 8, "float64"), (_ekf, 24, 8, "float32"),
                                             (_ekf, 256, 16, "float64"), (_ekf, 1024, 32, "float32"),
-                                            (_ekf, 128, 64, "float32"),      # k = 192: 24 block columns, streamed factorisation
+                                            (_ekf, 128, 64, "float32"),      # k = 192: 12 block columns of 16, streamed factorisation
                                             (_rot, 20, 6, "float64"), (_rot, 40, 27, "float32")])
 def test_fused_front_kernel_is_bitwise_the_separate_launches(make, n, m, dtype):
     from aruco_slam_amd.synthetic import SyntheticStream
@@ -742,7 +742,7 @@ def test_fused_front_kernel_is_bitwise_the_separate_launches(make, n, m, dtype):
 
 @pytest.mark.parametrize("make,n,m,tol", [(_ekf, 128, 64, 1e-9), (_rot, 40, 27, 1e-9)])
 def test_k192_vs_oracle(make, n, m, tol):
-    """Largest innovation the fused front kernel takes (k = 192 / 189: 24 block columns through the streamed
+    """Largest innovation the fused front kernel takes (k = 192 / 189: 12 block columns of 16 through the streamed
     factorisation of ekf_solve_big.h)."""
     from oracle.ekf_numpy import OracleEKF, OracleEKFRotations
     from aruco_slam_amd.synthetic import SyntheticStream
@@ -778,7 +778,7 @@ def test_large_k_runs_are_repeatable_bitwise():
 
 def test_c5_size_back_to_back_frames_fused_vs_separate_launches():
     """n=4096, m=64 (C5): the front kernel has more workgroups than the GPU has CUs (late-starting
-    chunks), the factorisation streams 24 block columns (history blocks re-read from the exchange buffer,
+    chunks), the factorisation streams 12 block columns (history blocks re-read from the exchange buffer,
     tag-checked), every bounded wait is long; 40 frames back to back through the sequence entry
     point, one filter at a time, must give the bits of the separate launches.  ``fused=True`` IS the
     fused kernel at this size (round 1 silently fell back to the stage kernels here)."""

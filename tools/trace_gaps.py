@@ -11,6 +11,7 @@ for r in rows:
 for k, v in dur.items():
     print(f"{k:40s} n={len(v):4d} mean {sum(v)/len(v):7.2f} us")
 # timeline of the last 12 kernels
-t0 = int(rows[-16]["Start_Timestamp"])
-for r in rows[-16:]:
+NT = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+t0 = int(rows[-NT]["Start_Timestamp"])
+for r in rows[-NT:]:
     print(f"{short(r['Kernel_Name']):32s} start {(int(r['Start_Timestamp'])-t0)/1e3:8.2f} end {(int(r['End_Timestamp'])-t0)/1e3:8.2f} queue {r.get('Queue_Id','?')}")
