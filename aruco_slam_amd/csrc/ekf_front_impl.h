@@ -595,22 +595,25 @@ __device__ __forceinline__ void fr_panel_stage(const EkfFrame& fr, double* slots
         const int cnt = NB - 1 - q;                    // blocks below the diagonal
         const int sl = q % FR_SLOTS;
         double* slot = slots + sl * SLOT;
-        // Dinv_q and y_q first (what W_q needs; y is the last thing the factorisation publishes of a column), polled on
-        // these five words per lane only: every chunk polling the bulk -- 24 KB per wave and round -- kept the
-        // factorisation's own stores waiting
+        // One attempt at the whole column (a chunk that is behind the factorisation finds it: one round trip).  A column
+        // that is not there yet is waited for QUIETLY: first on LDS until the previous column has arrived in this workgroup,
+        // then on ONE line (y_q, the last thing the factorisation publishes of a column), so that at most one wave per
+        // chunk polls memory.  (Every chunk polling Dinv and y -- 17 lines, 4 waves each -- from the moment it was ready:
+        // the factorisation's publication stores queued behind the polls, 5 - 7 us per block column instead of 2 at
+        // n=4096.)
         double dv[4], yv = 0.0;
-        for (int it = 0;; ++it) {
+        double v[NB - 1][4];
+        auto load_dy = [&]() {
 #pragma unroll
             for (int r = 0; r < 4; ++r) dv[r] = ekf_ldc(xdop + (size_t)(q * 4 + r) * 64 + lane);
             yv = ekf_ldc(xy + 16 * q + (lane & 15));
+        };
+        auto pend_dy = [&]() {
             bool pend = ekf_is_sent(yv);
 #pragma unroll
             for (int r = 0; r < 4; ++r) pend = pend || ekf_is_sent(dv[r]);
-            if (!__any(pend)) break;
-            if (it > EKF_SPIN_MAX) { spin_fail = 1; break; }
-            ekf_poll_sleep();
-        }
-        double v[NB - 1][4];
+            return __any(pend) != 0;
+        };
         auto fetch = [&]() {
 #pragma unroll
             for (int i = 0; i < NB - 1; ++i) {
@@ -620,7 +623,28 @@ __device__ __forceinline__ void fr_panel_stage(const EkfFrame& fr, double* slots
                 for (int r = 0; r < 4; ++r) v[i][r] = ekf_ldc(src + r * 64 + lane);
             }
         };
-        fetch();                                       // (in flight while the slot is waited for and Dinv / y go in)
+        load_dy();
+        fetch();
+        if (pend_dy()) {
+            if (q > 0) {
+                int it = 0;
+                while (flags[(q - 1) % FR_SLOTS] < (q - 1) / FR_SLOTS + 1) {
+                    if (++it > 64 * EKF_SPIN_MAX) { spin_fail = 1; break; }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+            for (int it = 0; ekf_is_sent(ekf_ldc(xy + 16 * q + (lane & 15))); ++it) {
+                if (it > EKF_SPIN_MAX) { spin_fail = 1; break; }
+                ekf_poll_sleep();
+            }
+            for (int it = 0;; ++it) {
+                load_dy();
+                if (!pend_dy()) break;
+                if (it > EKF_SPIN_MAX) { spin_fail = 1; break; }
+                ekf_poll_sleep();
+            }
+            fetch();
+        }
         if (q >= FR_SLOTS) {                           // the slot's previous column has been read by all four waves
             int it = 0;
             while (flags[4 + sl] < 4 * (q / FR_SLOTS)) {

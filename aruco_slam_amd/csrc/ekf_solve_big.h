@@ -33,11 +33,25 @@
 //                      [C] column b + 2:  t_i(b+2) = S_i,b+2 - sum_{q < b} L_iq L_b+2,q^T (history from memory; row b + 2's
 //                          blocks are staged in LDS once, each worker a sixth of them) - L_ib L_b+2,b^T
 //         publisher  : X_b, the L_ib and y_b of column b from LDS to memory; colready[b] when the stores are complete.
-//     Critical path per column: panel block (4 MFMAs) -> diagonal update (4 MFMAs) -> LDS -> chain (~3.3k cycles) -> LDS.
+//     Critical path per column: panel block (4 MFMAs) -> diagonal update (4 MFMAs) -> LDS -> chain (~3.3k cycles) -> LDS -- for
+//     the first block columns.  From b ~ 3 on the workers' [C] is longer than a chain and sets the period (measured at NB = 12,
+//     tools/chunk_stamps.py svb: 2.9 us at b = 1 growing to 5.5 - 6.5 us from b = 5 on; one worker at b = 6: [A] 0.5, [B] 0.5,
+//     the S blocks of column b + 2 0.6, six history terms 3.4 -- one memory round trip and then 6 x 4 dependent f64 MFMAs
+//     per row with two workers per SIMD -- last term 0.4).  Batching the history requests (eight blocks of a row per round
+//     trip), ordinary instead of agent-scope loads for them and requesting the S blocks a column ahead each changed nothing:
+//     the history sums are bound by the matrix pipe of the three SIMDs that are not the chain's.
 #pragma once
 #include "ekf_solve_device.h"
 
 #define SVB_WORKERS 6
+#ifdef SVB_DIAG      // (diagnostic builds, tools/chunk_stamps.py svb: per-column stamps of the publishing and the chain wave in
+                     // fr.stamps[0 .. 47], of worker SVB_DIAG_W during block column SVB_DIAG_B in [48 .. 55])
+#define SVB_STAMP(i) do { if (fr.stamps && lane == 0) fr.stamps[i] = wall_clock64(); } while (0)
+#define SVB_WSTAMP(i) do { if (fr.stamps && lane == 0 && widx == SVB_DIAG_W && b == SVB_DIAG_B) fr.stamps[48 + (i)] = wall_clock64(); } while (0)
+#else
+#define SVB_STAMP(i) do { } while (0)
+#define SVB_WSTAMP(i) do { } while (0)
+#endif
 
 __host__ __device__ constexpr int svb_lds_doubles(int nb) {
     // X (two slots) | L_ib of every row (NB + 1) | staged history of a pivot row (NB) | diagonal block | y (16 NB) | flags (3 NB + 8 ints)
@@ -85,6 +99,7 @@ __device__ __forceinline__ void sv_factor_big(const EkfFrame& fr, IO& io, double
     if (is_chain) {
         for (int b = 0; b < NB; ++b) {
             svb_wait(dready, b + 1);
+            SVB_STAMP(24 + b);
             sf64x4 m = sv_lds_get(dblk, lane);
             sf64x4 xop;
             int badnow;
@@ -127,7 +142,9 @@ __device__ __forceinline__ void sv_factor_big(const EkfFrame& fr, IO& io, double
                     io.put_y(b, (c >> 2) == 0 ? yi[0] : (c >> 2) == 1 ? yi[1] : (c >> 2) == 2 ? yi[2] : yi[3], c, g == (c & 3));
                 }
             }
+            SVB_STAMP(12 + b);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the column is in memory: it may be read back as history
+            SVB_STAMP(b);
             svb_post(colready + b, 1, lane);
         }
         return;
@@ -150,7 +167,9 @@ __device__ __forceinline__ void sv_factor_big(const EkfFrame& fr, IO& io, double
         svb_post(dready, 1, lane);
     }
     for (int b = 0; b < NB; ++b) {
+        SVB_WSTAMP(7);                                           // (the previous column's [C] is over)
         __syncthreads();                                         // X_b is there (and every reader of the previous column's LDS copies is done)
+        SVB_WSTAMP(0);
         const sf64x4 xop = sv_lds_get(xbuf + (b & 1) * 256, lane);
         // [A] the panel: L_ib = t_i(b) X_b^T
 #pragma unroll
@@ -164,6 +183,7 @@ __device__ __forceinline__ void sv_factor_big(const EkfFrame& fr, IO& io, double
                 svb_post(yflag + i, b + 1, lane);
             }
         }
+        SVB_WSTAMP(1);
         if (b + 1 >= NB) break;
         // [B] the last term of column b + 1; its diagonal block goes to the chain wave
 #pragma unroll
@@ -182,14 +202,17 @@ __device__ __forceinline__ void sv_factor_big(const EkfFrame& fr, IO& io, double
             }
         }
         const int p = b + 2;                                     // [C] column p = b + 2, beside chain b + 1
+        SVB_WSTAMP(2);
         if (p >= NB) continue;
         fetch_column(tnxt, p);
+        SVB_WSTAMP(3);
         // the pivot row's history -L_pq, q < b: staged once for all workers, a sixth each
         for (int q = widx; q < b; q += SVB_WORKERS) {
             svb_wait(colready + q, 1);
             sv_lds_put(prow + q * 256, io.hist_block(p, q, lane), lane);
             svb_post(pflag + q, p, lane);
         }
+        SVB_WSTAMP(4);
         for (int q = 0; q < b; ++q) {
             svb_wait(colready + q, 1);
             sf64x4 own[MR];
@@ -213,6 +236,7 @@ __device__ __forceinline__ void sv_factor_big(const EkfFrame& fr, IO& io, double
                 if (i >= p && i <= NB) sv_mm_sub(tnxt[s], piv, own[s]);
             }
         }
+        SVB_WSTAMP(5);
         // ... and the term of the column that has just been finished (q = b), from the LDS copies
 #pragma unroll
         for (int s = 0; s < MR; ++s) {
@@ -225,6 +249,7 @@ __device__ __forceinline__ void sv_factor_big(const EkfFrame& fr, IO& io, double
                 }
             }
         }
+        SVB_WSTAMP(6);
     }
 }
 

@@ -35,6 +35,14 @@ def main():
             for h in range(2):
                 print(f"  round {r} stage {h}: operands staged {us(1 + 4 * r + 2 * h):.2f}  MFMAs done {us(2 + 4 * r + 2 * h):.2f}")
         print("  support rows complete", us(10), " Jacobian in LDS", us(11))
+    if "svb" in sys.argv:
+        t0 = st[24]
+        print("  factorisation (us since the first chain started): column: chain starts / X in LDS / publisher's stores issued / complete")
+        for b in range(nb):
+            print(f"    {b:2d}: {us(24 + b):7.2f} {us(36 + b):7.2f} {us(12 + b):7.2f} {us(b):7.2f}")
+        t0 = st[48]
+        print("  one worker during one block column, us since its barrier: [A] done %.2f  [B] done %.2f  S blocks of column b+2 %.2f  pivot row staged %.2f  history terms %.2f  last term %.2f ; previous column's [C] ended %.2f" % tuple(us(48 + i) for i in (1, 2, 3, 4, 5, 6, 7)))
+        t0 = st[32]
     print("  A chunk in LDS", us(33))
     print("  substitution steps done:", " ".join(f"{us(34 + q):.2f}" for q in range(nb)))
     print("  W / dx stored", us(34 + nb))
