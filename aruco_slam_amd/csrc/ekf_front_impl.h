@@ -60,9 +60,9 @@ __host__ __device__ inline size_t fr_chunk_a_len(int kpad, bool fix, int elem) {
     const size_t st = elem == 4 ? (size_t)(FR_KS * 128 + FR_KS * 64 + 128 * 64) / 2 : (size_t)(2 * FR_KS64 * 64 + 64 * 64);
     return (fix && a < st) ? st : a;
 }
-// NB > 8 (k > 128): the four waves that do not substitute fetch whole block columns of the factor into LDS slots instead
+// NB >= 2: the four waves that do not substitute fetch whole block columns of the factor into LDS slots instead
 // (fr_panel_stage), see fr_panel.
-#define FR_STAGED_MIN_NB 9
+#define FR_STAGED_MIN_NB 2
 #define FR_SLOTS 4
 
 typedef double pf64x4 __attribute__((ext_vector_type(4)));
@@ -553,6 +553,7 @@ struct FrPre {
     double lqa[LG][4], dqn[4], yqn[4];
     unsigned long long smask;       // next-frame detections whose landmark owns this lane's column (duplicates possible)
     int sdim;
+    double st_old, q_old[4];        // EKF model: the old state of this lane's column / the old camera quaternion (wave 0)
 };
 template <int NB, int MODEL>
 __device__ __forceinline__ void fr_panel_pre(const EkfFrame& fr, FrPre<NB>& pre, const unsigned long long* smask_l, int wv, int col0, int lane) {
@@ -570,6 +571,17 @@ __device__ __forceinline__ void fr_panel_pre(const EkfFrame& fr, FrPre<NB>& pre,
         }
     }
     const int mycol = col0 + j;
+    // the old state of this wave's columns (nobody writes it before the injection at the end of fr_panel).  Requested here,
+    // before the A chunk is built: requested in fr_panel it was waited for at that function's first barrier -- a memory
+    // round trip between "A in LDS" and the first step of the substitution
+    pre.st_old = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pre.q_old[i] = 0.0;
+    if (MODEL == 0) {
+        if (mycol < fr.dims) pre.st_old = fr.state[mycol];
+        if (col0 == 0)
+            for (int i = 0; i < 4; ++i) pre.q_old[i] = fr.state[3 + i];
+    }
     pre.smask = fr.wsup ? smask_l[16 * wv + j] : 0ull;
     pre.sdim = (mycol >= EKF_CAM) ? (mycol - EKF_CAM) % EkfModel<MODEL>::LMD : 0;
 }
@@ -633,9 +645,11 @@ __device__ __forceinline__ void fr_panel_stage(const EkfFrame& fr, double* slots
                     __builtin_amdgcn_s_sleep(8);
                 }
             }
-            for (int it = 0; ekf_is_sent(ekf_ldc(xy + 16 * q + (lane & 15))); ++it) {
-                if (it > EKF_SPIN_MAX) { spin_fail = 1; break; }
-                ekf_poll_sleep();
+            if (NB >= 9) {      // (many chunks: one line first; few: Dinv and y at once, a round trip less between "published" and "used")
+                for (int it = 0; ekf_is_sent(ekf_ldc(xy + 16 * q + (lane & 15))); ++it) {
+                    if (it > EKF_SPIN_MAX) { spin_fail = 1; break; }
+                    ekf_poll_sleep();
+                }
             }
             for (int it = 0;; ++it) {
                 load_dy();
@@ -706,12 +720,8 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
         for (int r = 0; r < 4; ++r) t[b][r] = a_lds[(16 * b + g + 4 * r) * FR_ALD + 16 * wv + j];
     // the old state of this wave's columns (nobody writes it before the injection below)
     const int scol = col0 + j;
-    double st_old = 0.0, q_old[4] = {0.0, 0.0, 0.0, 0.0};
-    if (MODEL == 0) {
-        if (scol < fr.dims) st_old = fr.state[scol];
-        if (col0 == 0)
-            for (int i = 0; i < 4; ++i) q_old[i] = fr.state[3 + i];
-    }
+    const double st_old = pre.st_old;
+    const double q_old[4] = {pre.q_old[0], pre.q_old[1], pre.q_old[2], pre.q_old[3]};
     const double q_rn = (MODEL == 0 && col0 == 0) ? ekf_quat_rnorm(q_old) : 0.0;      // (here: not on the tail of the launch)
     double part = 0.0;
     // Prefetch (a chunk that is BEHIND the factorisation -- every chunk in the pipelined sequence mode, whose

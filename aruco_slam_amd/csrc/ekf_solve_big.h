@@ -42,6 +42,7 @@
 //     the history sums are bound by the matrix pipe of the three SIMDs that are not the chain's.
 #pragma once
 #include "ekf_solve_device.h"
+#include "ekf_solve_cw.h"
 
 #define SVB_WORKERS 6
 #ifdef SVB_DIAG      // (diagnostic builds, tools/chunk_stamps.py svb: per-column stamps of the publishing and the chain wave in
@@ -253,10 +254,14 @@ __device__ __forceinline__ void sv_factor_big(const EkfFrame& fr, IO& io, double
     }
 }
 
-// NB <= 8: every block in registers (sv_factor); beyond: the streamed version above
+// NB <= 6: one chain wave, no barriers (ekf_solve_cw.h); 7, 8: every block in registers, the chain on the row's owner
+// (sv_factor); beyond: the streamed version above
 template <int NB, class IO>
 __device__ __forceinline__ void sv_factor_any(const EkfFrame& fr, IO& io, double* lds, int& bad, int& badcol) {
-    if constexpr (NB <= 8) sv_factor<NB>(fr, io, lds, bad, badcol);
+    if constexpr (NB <= 6) sv_factor_cw<NB>(fr, io, lds, bad, badcol);
+    else if constexpr (NB <= 8) sv_factor<NB>(fr, io, lds, bad, badcol);
     else sv_factor_big<NB>(fr, io, lds, bad, badcol);
 }
-__host__ __device__ constexpr int sv_lds_doubles_any(int nb) { return nb <= 8 ? sv_lds_doubles(nb) : svb_lds_doubles(nb); }
+__host__ __device__ constexpr int sv_lds_doubles_any(int nb) {
+    return nb <= 6 ? svc_lds_doubles(nb) : nb <= 8 ? sv_lds_doubles(nb) : svb_lds_doubles(nb);
+}
