@@ -598,6 +598,11 @@ __device__ __forceinline__ void fr_panel_pre(const EkfFrame& fr, FrPre<NB>& pre,
 template <int NB>
 __device__ __forceinline__ void fr_panel_stage(const EkfFrame& fr, double* slots, volatile ekf_lds_int* flags, int w, int lane) {
     constexpr int SLOT = FrPre<NB>::SLOT;
+    // The LAST block column (Dinv and y, nothing below) is on the path to the end of the launch: published -> seen by a
+    // poll -> last substitution step -> W / dx / state.  One wave polling with one request in flight sees it a memory round
+    // trip and a half after it was published on average (2.2 us per round trip beside the previous frame's covariance
+    // update); the loaders that have no column left poll it as well, out of phase, and whoever has it first places it.
+    constexpr bool HELP = NB >= 2 && NB <= 8;
     const double* __restrict__ xlop = fr.xl;
     const double* __restrict__ xdop = fr.xl + fr.xl_dop;
     const double* __restrict__ xy = fr.xl + fr.xl_y;
@@ -659,6 +664,11 @@ __device__ __forceinline__ void fr_panel_stage(const EkfFrame& fr, double* slots
             }
             fetch();
         }
+        if (HELP && q == NB - 1) {                     // (the last column: whoever has it first places it, see below)
+            int won = 0;
+            if (lane == 0) won = __hip_atomic_fetch_add(const_cast<ekf_lds_int*>(flags) + 12, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0;
+            if (!__builtin_amdgcn_readfirstlane(won)) break;
+        }
         if (q >= FR_SLOTS) {                           // the slot's previous column has been read by all four waves
             int it = 0;
             while (flags[4 + sl] < 4 * (q / FR_SLOTS)) {
@@ -691,6 +701,45 @@ __device__ __forceinline__ void fr_panel_stage(const EkfFrame& fr, double* slots
             }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) flags[8 + sl] = q / FR_SLOTS + 1;
+    }
+    if (HELP && w != (NB - 1) % 4) {
+        constexpr int q = NB - 1, sl = q % FR_SLOTS;
+        double* slot = slots + sl * SLOT;
+        for (int d = (((NB - 1) % 4 - w) & 3); d > 0; --d) __builtin_amdgcn_s_sleep(24);      // (out of phase with the column's own loader)
+        for (int it = 0; flags[sl] < q / FR_SLOTS + 1; ++it) {
+            double dv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dv[r] = ekf_ldc(xdop + (size_t)(q * 4 + r) * 64 + lane);
+            const double yv = ekf_ldc(xy + 16 * q + (lane & 15));
+            bool pend = ekf_is_sent(yv);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pend = pend || ekf_is_sent(dv[r]);
+            if (!__any(pend)) {
+                int won = 0;
+                if (lane == 0) won = __hip_atomic_fetch_add(const_cast<ekf_lds_int*>(flags) + 12, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0;
+                if (__builtin_amdgcn_readfirstlane(won)) {
+                    if (q >= FR_SLOTS) {
+                        int it2 = 0;
+                        while (flags[4 + sl] < 4 * (q / FR_SLOTS)) {
+                            if (++it2 > 64 * EKF_SPIN_MAX) { spin_fail = 1; break; }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) slot[r * 64 + lane] = dv[r];
+                    if (lane < 16) slot[NB * 256 + lane] = yv;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 0) {
+                        flags[sl] = q / FR_SLOTS + 1;
+                        flags[8 + sl] = q / FR_SLOTS + 1;
+                    }
+                }
+                break;
+            }
+            if (it > EKF_SPIN_MAX) { spin_fail = 1; break; }
+            ekf_poll_sleep();
+        }
     }
     if (spin_fail && lane == 0) ekf_raise(fr, EKF_ST_TIMEOUT);
 }
@@ -964,8 +1013,8 @@ __device__ __forceinline__ void fr_panel(const EkfFrame& fr, const double* a_lds
     if (wv == 0 && lane == NB && fr_tag_stale(ekf_ldc(fr.xl + fr.xl_tag), fr.seqno)) ekf_raise(fr, EKF_ST_STALE_JAC);
 }
 
-#ifdef FR_CHUNK_DIAG      // (diagnostic builds: prologue stamps of chunk 0 in the slots of the factorisation role)
-#define FR_DIAG(i) do { if (fr.stamps && chunk == 0 && tid == 0) fr.stamps[i] = wall_clock64(); } while (0)
+#ifdef FR_CHUNK_DIAG      // (diagnostic builds: prologue stamps of chunk 0, role-level stamp mode, slots 41 .. 52)
+#define FR_DIAG(i) do { if (fr.stamps && !fr.stamps_heavy && chunk == 0 && tid == 0) fr.stamps[41 + (i)] = wall_clock64(); } while (0)
 #else
 #define FR_DIAG(i) do { } while (0)
 #endif
@@ -1030,7 +1079,7 @@ __device__ __forceinline__ void fr_role_chunk(const EkfFrame& fr, int chunk, dou
         nidx[tid - 64] = ((unsigned)ni >= (unsigned)fr.n_lm) ? 0 : ni;
     }
     if (tid == 0) { flag[1] = 0; flag[2] = 0; }
-    if (FrPre<NB>::STAGED && tid < 12) ekf_lds_flags(pshare)[tid] = 0;      // (staged substitution: slot flags)
+    if (FrPre<NB>::STAGED && tid < 16) ekf_lds_flags(pshare)[tid] = 0;      // (staged substitution: slot flags)
     __syncthreads();
     if (fr.wsup && tid < 64) {      // next-frame detections whose landmark owns column c (duplicates possible)
         unsigned long long mk = 0ull;

@@ -30,11 +30,12 @@ def main():
     us = lambda i: (st[i] - t0) / 100.0
     print(f"n={n} m={m} mode {f.backend.last_sequence_mode()}: chunk 0 of the last frame, us since its start (100 MHz clock)")
     if "diag" in sys.argv:
-        print("  indices / masks in LDS", us(0))
+        D = 41
+        print("  indices / masks in LDS", us(D + 0))
         for r in range(2):
             for h in range(2):
-                print(f"  round {r} stage {h}: operands staged {us(1 + 4 * r + 2 * h):.2f}  MFMAs done {us(2 + 4 * r + 2 * h):.2f}")
-        print("  support rows complete", us(10), " Jacobian in LDS", us(11))
+                print(f"  round {r} stage {h}: operands staged {us(D + 1 + 4 * r + 2 * h):.2f}  MFMAs done {us(D + 2 + 4 * r + 2 * h):.2f}")
+        print("  support rows complete", us(D + 10), " Jacobian in LDS", us(D + 11))
     if "svb" in sys.argv:
         t0 = st[24]
         print("  factorisation (us since the first chain started): column: chain starts / X in LDS / publisher's stores issued / complete")
