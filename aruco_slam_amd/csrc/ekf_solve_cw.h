@@ -44,6 +44,15 @@ __device__ __forceinline__ void svc_post(volatile ekf_lds_int* word, int value, 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) *word = value;
 }
+// The chain wave's posts: no wait for the block it has just written.  The LDS unit executes the ds instructions of ONE
+// wave in the order they were issued, so the flag write cannot overtake the data writes in front of it (a release fence
+// would be an `s_waitcnt lgkmcnt(0)`: ~100 cycles twice per block column on the critical path); the compiler barrier
+// keeps the program order, the readers acquire as usual.
+__device__ __forceinline__ void svc_post_in_order(volatile ekf_lds_int* word, int value, int lane) {
+    asm volatile("" ::: "memory");
+    if (lane == 0) *word = value;
+    asm volatile("" ::: "memory");
+}
 
 // f(integral_constant<int, B>) for B = B0 .. N - 1 while it returns true (block column indices have to be compile-time
 // constants: they index register arrays)
@@ -104,17 +113,20 @@ __device__ __forceinline__ void sv_factor_cw(const EkfFrame& fr, IO& io, double*
             }
             if (badnow && !bad) badcol = 100 + b;
             bad |= badnow;
+            sf64x4 p = {0.0, 0.0, 0.0, 0.0};
+            if (b + 1 < NB) {                                    // (row b + 1's blocks: requested before X_b goes out, used after)
+                svc_wait(dready + (b + 1), 1);
+                p = sv_lds_get(dep + (b + 1) * 512, lane);
+                d = sv_lds_get(dep + (b + 1) * 512 + 256, lane);
+            }
             sv_lds_put(xbuf + b * 256, xop, lane);
-            svc_post(xready, b + 1, lane);
+            svc_post_in_order(xready, b + 1, lane);
             if (b + 1 < NB) {
                 // row b + 1: its panel and its diagonal update here, straight into the next chain
-                svc_wait(dready + (b + 1), 1);
-                const sf64x4 p = sv_lds_get(dep + (b + 1) * 512, lane);
-                d = sv_lds_get(dep + (b + 1) * 512 + 256, lane);
                 const sf64x4 y = sv_mm(xop, p);
                 sv_mm_sub(d, y, y);
                 sv_lds_put(yb(b + 1, b), y, lane);
-                svc_post(yflag + (b + 1), b + 1, lane);
+                svc_post_in_order(yflag + (b + 1), b + 1, lane);
                 if (fr.wdbg) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) fr.lmat[(size_t)(EKF_RB * (b + 1) + c) * fr.ldl + EKF_RB * b + g + 4 * r] = y[r];

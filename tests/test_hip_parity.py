@@ -723,7 +723,10 @@ def test_checkpoint_resume_is_bitwise(tmp_path, make, dtype):
 @pytest.mark.parametrize("make,n,m,dtype", [(_ekf, 24, 8, "float64"), (_ekf, 24, 8, "float32"),
                                             (_ekf, 256, 16, "float64"), (_ekf, 1024, 32, "float32"),
                                             (_ekf, 128, 64, "float32"),      # k = 192: 12 block columns of 16, streamed factorisation
-                                            (_ekf, 96, 46, "float32"),       # k = 138: 9 block columns, the smallest staged substitution
+                                            (_ekf, 64, 20, "float32"),       # k = 60: 4 block columns (chain-wave factorisation, one row per worker)
+                                            (_ekf, 64, 26, "float64"),       # k = 78: 5
+                                            (_ekf, 96, 38, "float32"),       # k = 114: 8 (sv_factor: the chain on the row's owner)
+                                            (_ekf, 96, 46, "float32"),       # k = 138: 9 block columns, the streamed factorisation
                                             (_ekf, 96, 50, "float64"),       # k = 150: 10
                                             (_ekf, 200, 57, "float32"),      # k = 171: 11
                                             (_rot, 40, 21, "float32"),       # EKF_Rotations k = 147: 10
