@@ -34,12 +34,12 @@
 //                          blocks are staged in LDS once, each worker a sixth of them) - L_ib L_b+2,b^T
 //         publisher  : X_b, the L_ib and y_b of column b from LDS to memory; colready[b] when the stores are complete.
 //     Critical path per column: panel block (4 MFMAs) -> diagonal update (4 MFMAs) -> LDS -> chain (~3.3k cycles) -> LDS -- for
-//     the first block columns.  From b ~ 3 on the workers' [C] is longer than a chain and sets the period (measured at NB = 12,
-//     tools/chunk_stamps.py svb: 2.9 us at b = 1 growing to 5.5 - 6.5 us from b = 5 on; one worker at b = 6: [A] 0.5, [B] 0.5,
-//     the S blocks of column b + 2 0.6, six history terms 3.4 -- one memory round trip and then 6 x 4 dependent f64 MFMAs
-//     per row with two workers per SIMD -- last term 0.4).  Batching the history requests (eight blocks of a row per round
-//     trip), ordinary instead of agent-scope loads for them and requesting the S blocks a column ahead each changed nothing:
-//     the history sums are bound by the matrix pipe of the three SIMDs that are not the chain's.
+//     the first block columns.  From b ~ 3 on the workers' [C] is longer than a chain and sets the period (NB = 12,
+//     tools/chunk_stamps.py svb: 2.9 us at b = 1 growing to 5.5 - 6.5 us from b = 5 on).  One worker at b = 6, first version
+//     (a request, a flag wait and four dependent MFMAs per history term): [A] 0.5, [B] 0.5, S blocks of column b + 2 0.6, six
+//     history terms 3.4, last term 0.4 us.  Now the requests of a row go out together (one round trip, ~0.9 us) and the terms
+//     run on four accumulators, one per k-slice: six terms 1.8 us; n=1024 m=64 pipelined 71.3 -> 65.0 us per frame, n=4096
+//     m=64 367 -> 362.  (Also tried: all flags and pivot blocks of a batch before its MFMAs -- 48 more registers, slower.)
 #pragma once
 #include "ekf_solve_device.h"
 #include "ekf_solve_cw.h"
@@ -207,36 +207,73 @@ __device__ __forceinline__ void sv_factor_big(const EkfFrame& fr, IO& io, double
         if (p >= NB) continue;
         fetch_column(tnxt, p);
         SVB_WSTAMP(3);
-        // the pivot row's history -L_pq, q < b: staged once for all workers, a sixth each
-        for (int q = widx; q < b; q += SVB_WORKERS) {
-            svb_wait(colready + q, 1);
-            sv_lds_put(prow + q * 256, io.hist_block(p, q, lane), lane);
-            svb_post(pflag + q, p, lane);
-        }
-        SVB_WSTAMP(4);
-        for (int q = 0; q < b; ++q) {
-            svb_wait(colready + q, 1);
-            sf64x4 own[MR];
+        if (b > 0) {
+            // History terms q < b: every request of a batch -- the worker's share of the pivot row, then up to HD blocks of a
+            // row -- goes out before the first result is used (one memory round trip per batch; first version: one per term)
+            svb_wait(colready + (b - 1), 1);                       // (the publisher posts the columns in order)
+            SVB_WSTAMP(8);
+            constexpr int PV = (NB - 2 + SVB_WORKERS - 1) / SVB_WORKERS;
+            sf64x4 pv[PV];
 #pragma unroll
-            for (int s = 0; s < MR; ++s) {                       // (all requests of the step first)
-                const int i = row_of(s);
-                if (i >= p && i <= NB) {
-                    if (i == NB) {
+            for (int n = 0; n < PV; ++n) pv[n] = io.hist_block(p, min(widx + SVB_WORKERS * n, b - 1), lane);
+            bool staged = false;
+            auto stage = [&]() {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) own[s][r] = -yvec[EKF_RB * q + g + 4 * r];
-                    } else {
-                        own[s] = io.hist_block(i, q, lane);
+                for (int n = 0; n < PV; ++n) {
+                    const int q = widx + SVB_WORKERS * n;
+                    if (q < b) {
+                        sv_lds_put(prow + q * 256, pv[n], lane);
+                        svb_post(pflag + q, p, lane);
                     }
                 }
-            }
-            svb_wait(pflag + q, p);
-            const sf64x4 piv = sv_lds_get(prow + q * 256, lane);
+                staged = true;
+            };
+            constexpr int HD = 6;
 #pragma unroll
             for (int s = 0; s < MR; ++s) {
                 const int i = row_of(s);
-                if (i >= p && i <= NB) sv_mm_sub(tnxt[s], piv, own[s]);
+                if (i < p || i > NB) continue;
+                // Four accumulators, one per k-slice of the 16 x 16 x 16 product, summed at the end: with one accumulator every
+                // term is four DEPENDENT f64 MFMAs (~200 cycles each with two workers per SIMD: 0.37 us per term measured), with
+                // four the terms of a row are issue-bound.
+                sf64x4 hacc[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hacc[r] = sf64x4{0.0, 0.0, 0.0, 0.0};
+                auto term = [&](const sf64x4& pivb, const sf64x4& ownb) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hacc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pivb[r], ownb[r], hacc[r], 0, 0, 0);
+                };
+                if (i == NB) {                                     // the residual row: its history is y, in LDS
+                    if (!staged) stage();
+                    for (int q = 0; q < b; ++q) {
+                        sf64x4 own;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) own[r] = -yvec[EKF_RB * q + g + 4 * r];
+                        svb_wait(pflag + q, p);
+                        term(sv_lds_get(prow + q * 256, lane), own);
+                    }
+                } else {
+                    for (int q0 = 0; q0 < b; q0 += HD) {
+                        sf64x4 own[HD];
+#pragma unroll
+                        for (int d = 0; d < HD; ++d) own[d] = io.hist_block(i, min(q0 + d, b - 1), lane);
+                        if (!staged) { stage(); SVB_WSTAMP(9); }
+#pragma unroll
+                        for (int d = 0; d < HD; ++d) {
+                            if (q0 + d < b) {
+                                svb_wait(pflag + (q0 + d), p);
+                                if (d == 0 && q0 == 0) SVB_WSTAMP(10);
+                                term(sv_lds_get(prow + (q0 + d) * 256, lane), own[d]);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tnxt[s][r] += (hacc[0][r] + hacc[1][r]) + (hacc[2][r] + hacc[3][r]);
             }
+            if (!staged) stage();
         }
+        SVB_WSTAMP(4);
         SVB_WSTAMP(5);
         // ... and the term of the column that has just been finished (q = b), from the LDS copies
 #pragma unroll

@@ -43,6 +43,7 @@ def main():
             print(f"    {b:2d}: {us(24 + b):7.2f} {us(36 + b):7.2f} {us(12 + b):7.2f} {us(b):7.2f}")
         t0 = st[48]
         print("  one worker during one block column, us since its barrier: [A] done %.2f  [B] done %.2f  S blocks of column b+2 %.2f  pivot row staged %.2f  history terms %.2f  last term %.2f ; previous column's [C] ended %.2f" % tuple(us(48 + i) for i in (1, 2, 3, 4, 5, 6, 7)))
+        print("    batched form: column b-1 ready %.2f  pivot share staged %.2f  first pivot block there %.2f" % (us(56), us(57), us(58)))
         t0 = st[32]
     print("  A chunk in LDS", us(33))
     print("  substitution steps done:", " ".join(f"{us(34 + q):.2f}" for q in range(nb)))
