@@ -802,7 +802,12 @@ int ekf_observe_sequence_device(ekf_filter* f, const int32_t* lm_index_dev, cons
     // cannot run beside them.
     const int dims_now = f->dims();
     const int kpad_now = (int)round_up(f->lay.rd * m, EKF_RB);
-    const bool auto_on = !(dims_now > 9000 && kpad_now > 96);
+    // (measured, profiles/r03_mode_select.txt.  EKF model: pipelined wins everywhere except N > 9000 with k > 96, where the front
+    // kernel's workgroups and the macro-tile update cannot share CUs.  EKF_Rotations: its chunks complete 10 + 10 m support rows
+    // per frame in the pipelined form; from k = 91 (m = 13) on the serial order is faster: 28.2k vs 24.3k updates/s at n=100
+    // m=13, 25.5k vs 16.4k at m=16, 15.7k vs 12.7k at n=200 m=21, 9.3k vs 9.1k at n=400 m=27; below, pipelined: 41.0k vs
+    // 32.5k at n=100 m=9)
+    const bool auto_on = !(dims_now > 9000 && kpad_now > 96) && !(f->cfg.model == EKF_MODEL_ROTATIONS && kpad_now > 64);
     const bool want = (f->cfg.flags & 2) != 0 || ((f->cfg.flags & 1) == 0 && auto_on);
     bool pipelined = want && f->lay.has_cov2 && !f->timing && frames >= 2 && (f->cfg.flags & 4) == 0 && kpad_now <= 192;
     if (pipelined && f->la_ok < 0) {
