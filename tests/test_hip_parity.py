@@ -387,6 +387,36 @@ def test_pipelined_sequence_mode_beyond_96_rows_is_bitwise_the_serial_order(n, m
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("m,want", [(6, "pipelined"), (16, "serial")])
+def test_sequence_mode_chosen_by_size_for_ekf_rotations(m, want):
+    """The size rule (profiles/r03_mode_select.txt): EKF_Rotations pipelines up to k = 64 rows, serial order beyond (its
+    pipelined form is slower there); either way the results are those of per-frame calls, bit for bit."""
+    import torch
+    from aruco_slam_amd.filters.ekf_with_rotations import euler_xyz_to_quat
+    from aruco_slam_amd.synthetic import SyntheticStream
+    n = 40
+    s = SyntheticStream(n, m, seed=4, rvec_sigma=0.05)
+    boot = list(s.bootstrap())
+    frames = [(ids.copy(), poses.copy()) for ids, poses in s.steady(8)]
+    outs = []
+    for seq in (True, False):
+        flt = _rot(max_landmarks=n, max_visible=m, cov_dtype="float32")
+        for ids, poses in boot:
+            flt.observe(ids, poses)
+        if seq:
+            idx = torch.tensor(np.stack([f[0] for f in frames]), dtype=torch.int32, device="cuda")
+            z = np.stack([np.hstack((f[1][:, :3], euler_xyz_to_quat(f[1][:, 3:6]))) for f in frames])
+            flt.backend.observe_sequence(idx, torch.tensor(z, dtype=torch.float64, device="cuda"), None)
+            assert flt.backend.last_sequence_mode() == want
+            flt.backend.sync()
+        else:
+            for ids, poses in frames:
+                flt.observe(ids, poses)
+        outs.append((flt.state, flt.uncertainty))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1])
+
+
 def test_pipelined_sequence_mode_at_headline_size_is_bitwise_the_serial_order():
     """n=1024, m=32, f32 covariance: the sequence entry point picks the pipelined mode by itself here (front kernel
     of frame t+1 beside the covariance update of frame t on a second covariance buffer, support entries of P completed
