@@ -428,6 +428,9 @@ int sync_and_check(ekf_filter* f, int state_count = 0) {
             return fail(EKF_ERR_NUMERIC, "internal: exchange wait timed out in the front kernel (status " +
                                              std::to_string(st) + ")");
         const int32_t* info = reinterpret_cast<const int32_t*>(f->readback);
+        if (info[2] >= 200)      // (ekf_solve_cw.h: a bounded wait on one of the factorisation's LDS flag words ran out; should never happen)
+            return fail(EKF_ERR_NUMERIC, "internal: a wait inside the factorisation workgroup timed out (flag word " +
+                                             std::to_string(info[2] - 200) + ")");
         return fail(EKF_ERR_NUMERIC, "innovation covariance S was not positive definite (block column " +
                                          std::to_string(info[2] - 100) + ", wave mask " + std::to_string(info[1]) + ")");
     }

@@ -32,13 +32,16 @@ __host__ __device__ constexpr int svc_lds_doubles(int nb) {
     return nb * 256 + (nb + 1) * nb * 256 + nb * 512 + (2 * nb + 2 + 1) / 2 + 8;
 }
 
-__device__ __forceinline__ void svc_wait(volatile ekf_lds_int* word, int want) {
+// (bounded: a poster that never comes would be a bug, not a hang -- the caller then reports the factorisation as failed)
+__device__ __forceinline__ bool svc_wait_ok(volatile ekf_lds_int* word, int want) {
     int it = 0;
+    bool ok = true;
     while (*word < want) {
-        if (++it > (1 << 22)) break;                 // (bounded: a poster that never comes would be a bug, not a hang)
+        if (++it > (1 << 22)) { ok = false; break; }
         __builtin_amdgcn_s_sleep(1);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return ok;
 }
 __device__ __forceinline__ void svc_post(volatile ekf_lds_int* word, int value, int lane) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -77,6 +80,13 @@ __device__ __forceinline__ void sv_factor_cw(const EkfFrame& fr, IO& io, double*
     for (int e = tid; e < 2 * NB + 2; e += SV_T) xready[e] = 0;
     __syncthreads();
     const bool is_chain = wave == 0, is_pub = wave == 4;
+    // a wait that ran out: the factorisation counts as failed (status bit through the caller), block column code 200 + flag
+    auto svc_wait = [&](volatile ekf_lds_int* word, int want) {
+        if (!svc_wait_ok(word, want)) {
+            if (!bad) badcol = 200 + (int)(word - xready);
+            bad = 1;
+        }
+    };
     auto yb = [&](int i, int b) { return ybuf + ((size_t)i * NB + b) * 256; };
     // (light stamps, taken by the publishing wave, whose stores delay nobody: [0] start, [2 + 2 b] X_b seen)
     long long* stl = (fr.stamps && !fr.stamps_heavy && is_pub && lane == 0) ? fr.stamps : nullptr;
