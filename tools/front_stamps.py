@@ -25,13 +25,14 @@ print("fused front kernel timeline, us since the earliest stamp (100 MHz wall cl
 print("S-block wg0 start",us(60),"  measure wg published",us(55),"  S-block wg nS-1 stored",us(61))
 print("factor: start",us(62)," end",us(63))
 if not light: print("  cycles: blocks into registers",st[1]-st[0], " per wave:", [int(st[24+w]-st[0]) for w in range(8)])
-if light: print('  barrier of block column b (cycles since the start of the factorisation, publishing wave):', [int(st[2+2*b]-st[0]) for b in range(nb)])
+if light: print('  X_b in LDS, seen by the publishing wave (cycles since the start of the factorisation):', [int(st[2+2*b]-st[0]) for b in range(nb)])
 for b in range(0 if light else nb):
     prev = st[1] if b == 0 else st[3+2*(b-1)]
     print("  col",b," chain phase + barrier",st[2+2*b]-prev," panel + barrier + urgent update",st[3+2*b]-st[2+2*b],
           "  (chain alone %d; from the barrier: next owner's panel posted +%d, next chain starts +%d)" % (
               (st[48+2*b]-st[47+2*b]) if b < 4 else (st[49+2*b]-st[48+2*b]), st[16+b]-st[2+2*b],
               ((st[47+2*(b+1)] if b+1 < 4 else st[48+2*(b+1)]) - st[2+2*b]) if b+1 < nb else 0))
-print("chunk0: start",us(32)," indices in LDS",us(41)," operands staged",us(45)," MFMAs done",us(46)," tile done (wave 0)",us(42)," all tiles",us(43)," Jacobian in LDS",us(44)," picked",us(14)," prefetch issued",us(15)," A in LDS",us(33))
+if light: print("chunk0: start",us(32)," A in LDS",us(33), "  (prologue detail: tools/chunk_stamps.py ... diag with a -DFR_CHUNK_DIAG build)")
+else: print("chunk0: start",us(32)," indices in LDS",us(41)," operands staged",us(45)," MFMAs done",us(46)," tile done (wave 0)",us(42)," all tiles",us(43)," Jacobian in LDS",us(44)," picked",us(14)," prefetch issued",us(15)," A in LDS",us(33))
 for q in range(nb): print("  step",q,"done",us(34+q))
 print("  W/dx stored",us(34+nb))

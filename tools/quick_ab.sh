@@ -10,5 +10,5 @@ for v in "$@"; do
   timeout -k 10 120 python tools/front_stamps.py seq light > $out/${v}_stamps_light.log 2>&1 || { tail -5 $out/${v}_stamps_light.log; exit 1; }
   timeout -k 10 200 python tools/pipe_probe.py 1024 32 2000 > $out/${v}_pipe.log 2>&1 || exit 1
   timeout -k 10 600 python -m pytest tests -m gpu -q -x -p no:cacheprovider -k "bitwise or fused or pipelined or intermediates or k192 or g2_teacher" > $out/${v}_pytest.log 2>&1
-  echo "== $v"; tail -2 $out/${v}_pytest.log; grep -E "factor:|barrier of|S-block|step 5|W/dx" $out/${v}_stamps_light.log; grep "us/frame" $out/${v}_pipe.log
+  echo "== $v"; tail -2 $out/${v}_pytest.log; grep -E "factor:|X_b in LDS|S-block|step 5|W/dx" $out/${v}_stamps_light.log; grep "us/frame" $out/${v}_pipe.log
 done

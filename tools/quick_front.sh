@@ -8,4 +8,4 @@ timeout -k 10 120 python tools/front_stamps.py seq light > $out/stamps_seq_light
 timeout -k 10 120 python tools/front_stamps.py > $out/stamps_serial.log 2>&1 || exit 1
 timeout -k 10 200 python tools/pipe_probe.py 1024 32 2000 > $out/pipe_c3.log 2>&1 || exit 1
 timeout -k 10 600 python -m pytest tests -m gpu -q -x -p no:cacheprovider -k "bitwise or fused or pipelined or intermediates or k192 or g2_teacher" > $out/pytest.log 2>&1
-tail -3 $out/pytest.log; grep -v amdgpu.ids $out/stamps_seq.log; grep -E "factor:|barrier of|S-block|step 5|W/dx" $out/stamps_seq_light.log; cat $out/pipe_c3.log | grep us/frame
+tail -3 $out/pytest.log; grep -v amdgpu.ids $out/stamps_seq.log; grep -E "factor:|X_b in LDS|S-block|step 5|W/dx" $out/stamps_seq_light.log; cat $out/pipe_c3.log | grep us/frame
